@@ -1,0 +1,189 @@
+/*
+ * rtmi.h — C ABI of the MI355X-native path-tracing hot path (librtmi.so).
+ *
+ * This is the drop-in boundary for the per-pixel trace loop of
+ * tigert1998/ray-tracing-cuda.  Every entry point names the reference
+ * interface it replaces (paths relative to /root/reference/ray-tracing-cuda/).
+ * The reference's host driver (`Main` / `DistributedMain`, utils.cu:132-242)
+ * performs, in order: allocate states+image -> CudaRandomInit kernel ->
+ * user `init_world` callback -> PathTracing kernel -> D2H -> (MPI reduce) ->
+ * JPEG.  The calls below are those steps with plain pointers and sizes.
+ *
+ * Conventions
+ *   - All functions return 0 on success or a negative rtmi_status; the message
+ *     is available from rtmi_last_error() (thread-local).  The reference aborts
+ *     through glog CHECK (utils.cu:143-144); the C++ wrappers in
+ *     ray-tracing-cuda_amd/api/utils.cuh turn a non-zero status into the same CHECK failure.
+ *   - `d_*` pointers are device (HBM) pointers owned by the caller.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  All
+ *     device work is enqueued on it; functions documented "synchronous" wait
+ *     for it before returning.
+ *   - There is NO CPU fallback: every compute entry point fails with
+ *     RTMI_ERR_NO_DEVICE when no gfx950-class device is usable.
+ *
+ * Pixel ownership (multi-GPU): the frame is cut into 8x8-pixel tiles numbered
+ * row-major; rank r of world_size G owns tiles t with t % G == r.  A rank's
+ * pixels are addressed by *work item* q in [0, rtmi_frame_work_items()):
+ * local tile q/64, pixel-in-tile q%64 (row-major 8x8).  RNG states and the
+ * radiance buffer of a rank are indexed by q ("tile-major").  Every pixel keeps
+ * cuRAND subsequence == its GLOBAL index i*width+j, so the image is
+ * bit-identical for every world_size.  Work items that fall outside the image
+ * (ragged right/bottom tiles) are inert padding.
+ */
+#ifndef RTMI_H_
+#define RTMI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_VERSION 1
+#define RTMI_TILE 8            /* tile edge in pixels; 64 work items per tile = one wavefront */
+#define RTMI_STATE_WORDS 6     /* live words of curandState: d, v[0..4] */
+
+typedef enum rtmi_status {
+  RTMI_OK = 0,
+  RTMI_ERR_INVALID = -1,    /* bad argument / scene not committed / handle out of range */
+  RTMI_ERR_NO_DEVICE = -2,  /* HIP runtime or device unavailable */
+  RTMI_ERR_HIP = -3,        /* a HIP call failed; see rtmi_last_error() */
+  RTMI_ERR_CAPACITY = -4,   /* HitableList::kMaxHitables (1024) exceeded, hitable_list.cuh:10 */
+  RTMI_ERR_DEPTH = -5       /* max_depth outside [0, RTMI_MAX_DEPTH] */
+} rtmi_status;
+
+#define RTMI_MAX_DEPTH 64      /* TRACE_DEPTH_LIMIT is 10 in ray_tracing.cu:10; BASELINE configs use 8/10/50 */
+#define RTMI_MAX_HITABLES 1024 /* hitable_list.cuh:10 */
+
+typedef struct rtmi_scene rtmi_scene; /* opaque; replaces the device-resident HitableList + Camera pair */
+
+/* Frame + shard description; replaces the (height, width, spp, post_processing)
+ * arguments of PathTracing (ray_tracing.cuh:19-21) and the rank/world_size of
+ * DistributedMain (utils.cu:186-189). */
+typedef struct rtmi_frame {
+  int32_t height;
+  int32_t width;
+  int32_t spp;          /* samples per pixel rendered by THIS call */
+  int32_t max_depth;    /* TRACE_DEPTH_LIMIT, ray_tracing.cu:10,23 */
+  int32_t post_process; /* 1: out = sqrt(clamp(sum/spp,0,1)) (ray_tracing.cu:78-83); 0: raw sum */
+  int32_t rank;         /* tile shard owner, 0 <= rank < world_size */
+  int32_t world_size;   /* number of shards (GPUs) */
+} rtmi_frame;
+
+const char *rtmi_last_error(void);
+int rtmi_version(void);
+/* Number of usable GPUs (0 when there is none); never fails. */
+int rtmi_device_count(void);
+
+/* ------------------------------------------------------------------ scene --
+ * Host-side recording of the scene graph, one call per reference constructor.
+ * Texture / material calls return a handle >= 0 (or a negative rtmi_status).
+ * Hitables are appended to the world in call order == HitableList::Append
+ * order (hitable_list.cu:27-29); list order decides ties (hitable_list.cu:18). */
+rtmi_scene *rtmi_scene_create(void);
+void rtmi_scene_destroy(rtmi_scene *s);
+
+int rtmi_constant_texture(rtmi_scene *s, const float rgb[3]);                 /* textures/constant_texture.cu:7-9 */
+int rtmi_image_texture(rtmi_scene *s, const uint8_t *rgba, int height, int width,
+                       size_t pitch_bytes);                                   /* textures/image_texture.cu:17-38 (host RGBA8, point/wrap) */
+int rtmi_lambertian(rtmi_scene *s, const float rgb[3]);                        /* lambertian.cu:14-17 */
+int rtmi_lambertian_tex(rtmi_scene *s, int texture);                           /* lambertian.cu:9-12 */
+int rtmi_metal(rtmi_scene *s, const float rgb[3], float fuzz);                 /* metal.cu:7-10 */
+int rtmi_dielectric(rtmi_scene *s, const float rgb[3], double refractive_index); /* dielectric.cu:10-14 */
+int rtmi_diffuse_light(rtmi_scene *s, int texture);                            /* diffuse_light.cu:15-17 */
+
+int rtmi_add_sphere(rtmi_scene *s, const float center[3], double radius, int material);       /* sphere.cu:7-9 */
+int rtmi_add_triangle(rtmi_scene *s, const float p[9], int material);                           /* triangle.cu:6-9 */
+int rtmi_add_parallelogram(rtmi_scene *s, const float p[9], int material);                      /* parallelogram.cu:10-15 */
+int rtmi_add_parallelepiped(rtmi_scene *s, const float p[12], int material);                    /* parallelepiped.cu:8-18 */
+typedef void (*rtmi_transform_fn)(const float in[3], float out[3], void *user);
+int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int material,
+                                    rtmi_transform_fn transform, void *user);                   /* parallelepiped.cu:34-55 */
+int rtmi_add_sky(rtmi_scene *s);                                                                /* sky.cu:16 */
+/* BVH<Face<HasTexCoord>,AABB>(faces, n, material) (bvh.cuh:170-173).  faces:
+ * n*9 floats; uvs: n*6 floats or NULL (Face<false>); material < 0 keeps
+ * "material_ptr_ == nullptr" (bvh.cuh:178).  leaf_max is BVHNode::kMin (2048,
+ * bvh.cuh:105); pass 0 for the reference value. */
+int rtmi_add_bvh(rtmi_scene *s, const float *faces, const float *uvs, int n, int material, int leaf_max);
+
+int rtmi_camera_pinhole(rtmi_scene *s, const float pos[3], const float look_at[3], const float up[3],
+                        double fov, double aspect);                                              /* camera.cu:24-38 */
+int rtmi_camera_defocus(rtmi_scene *s, const float pos[3], const float look_at[3], const float up[3],
+                        double fov, double aspect, double aperture, double focus_distance);     /* camera.cu:6-22 */
+int rtmi_camera_raw(rtmi_scene *s, const float pos[3], const float lower_left[3], const float horizontal[3],
+                    const float vertical[3]);                                                    /* camera.cu:40-47 */
+/* position, lower_left_corner, horizontal, vertical, u, v, w (21 floats) */
+int rtmi_camera_get(const rtmi_scene *s, float out[21]);
+
+/* Flatten the recorded graph into the device layout and upload it to the
+ * current HIP device.  Synchronous.  Replaces the point in Main where
+ * init_world has run and cudaDeviceSynchronize returns (utils.cu:148-152). */
+int rtmi_scene_commit(rtmi_scene *s);
+/* Counts of the flattened scene: {world entries, spheres, parallelograms (incl.
+ * box faces), triangles, bvh faces, bvh nodes, materials, textures}. */
+int rtmi_scene_stats(const rtmi_scene *s, int64_t out[8]);
+/* Algorithmic bytes one closest-hit query consults; BVH scenes
+ * need the measured per-ray node/face visits and report only the fixed part. */
+int64_t rtmi_scene_bytes_per_ray(const rtmi_scene *s);
+
+/* ------------------------------------------------------------------ frame -- */
+/* Work items (pixels incl. ragged-tile padding) owned by frame->rank. */
+int64_t rtmi_frame_work_items(const rtmi_frame *f);
+/* Global pixel index (i*width+j) of work item q of this shard, or -1 for padding. */
+int64_t rtmi_frame_pixel_of(const rtmi_frame *f, int64_t q);
+/* Bytes the caller must allocate for d_states / d_tiles of this shard. */
+size_t rtmi_states_bytes(const rtmi_frame *f);   /* 6 planes of uint32[work_items] (struct-of-arrays) */
+size_t rtmi_tiles_bytes(const rtmi_frame *f);    /* float[work_items][3] */
+
+/* -------------------------------------------------------------------- RNG --
+ * Replaces CudaRandomInit<<<>>>(seed, states, n) (utils.cu:43-47,146,202):
+ * state(q) = curand_init(seed, subsequence = global pixel index, offset 0).
+ * Asynchronous on `stream`. */
+int rtmi_rng_init(uint64_t seed, const rtmi_frame *f, void *d_states, void *stream);
+/* Host copy of curand_init(seed, subsequence, 0): {d, v0..v4}. */
+int rtmi_rng_host_state(uint64_t seed, uint64_t subsequence, uint32_t state[RTMI_STATE_WORDS]);
+/* CudaRandomFloat(min, max, state) on a host state (utils.cuh:22-27); scene
+ * programs that draw their layout from pixel 0's stream (scenes/spheres.cu:105)
+ * use this and then store the advanced state with rtmi_rng_set_state. */
+float rtmi_rng_host_random_float(float min, float max, uint32_t state[RTMI_STATE_WORDS]);
+/* Overwrite / read back the state of work item q.  Synchronous. */
+int rtmi_rng_set_state(const rtmi_frame *f, void *d_states, int64_t q, const uint32_t state[RTMI_STATE_WORDS],
+                       void *stream);
+int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uint32_t state[RTMI_STATE_WORDS],
+                       void *stream);
+
+/* ----------------------------------------------------------------- render --
+ * Replaces PathTracing<<<grid,block>>>(world, camera, H, W, spp, post, states,
+ * out) (ray_tracing.cu:56-85; launches utils.cu:158-163, 216-221) for the
+ * pixels of frame->rank.  d_tiles receives float[work_items][3] (tile-major);
+ * d_ray_counts (nullable) receives the per-pixel number of closest-hit queries
+ * issued by Trace (ray_tracing.cu:22).  RNG states are advanced in place.
+ * Asynchronous on `stream`. */
+int rtmi_render(const rtmi_scene *s, const rtmi_frame *f, void *d_states, float *d_tiles,
+                uint32_t *d_ray_counts, void *stream);
+/* Total closest-hit queries of the most recent rtmi_render on this scene
+ * (waits for `stream`). */
+int rtmi_last_ray_total(const rtmi_scene *s, uint64_t *out_rays, void *stream);
+
+/* d_all_tiles holds the tile-major buffers of ranks 0..world_size-1 back to
+ * back (what an RCCL gather to the root produces; world_size==1: the buffer
+ * rtmi_render wrote).  Writes the row-major float[H*W][3] image the reference
+ * keeps in d_image (ray_tracing.cu:84).  Asynchronous on `stream`. */
+int rtmi_untile(const rtmi_frame *f, const float *d_all_tiles, float *d_image, void *stream);
+/* Same for per-pixel ray counts. */
+int rtmi_untile_u32(const rtmi_frame *f, const uint32_t *d_all_counts, uint32_t *d_image_counts, void *stream);
+
+/* GatherImageData's root-side step on a summed image (utils.cu:126-129):
+ * rgb = sqrt(clamp(rgb / spp, 0, 1)), in place over n_pixels*3 floats. */
+int rtmi_post_process(float *d_image, int64_t n_pixels, int spp, void *stream);
+/* GetWorkload (utils.cu:111-113). */
+int rtmi_get_workload(int rank, int world_size, int spp);
+
+/* Kernel launch configuration knobs (0 = library default). */
+int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H_ */

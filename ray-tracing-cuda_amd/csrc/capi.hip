@@ -1,0 +1,477 @@
+// C ABI of librtmi.so (declared in include/rtmi.h).  Thin glue: argument
+// checking, the host-side scene recorder, uploads, and kernel launches.  There is
+// deliberately no CPU rendering path in this library.
+#include <hip/hip_runtime.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <unordered_map>
+
+#include "../../include/rtmi.h"
+#include "kernels.h"
+#include "scene.h"
+#include "xorwow.h"
+
+using namespace rtmi;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+  g_err = msg;
+  return code;
+}
+static int hip_fail(hipError_t e, const char *what) {
+  return fail(RTMI_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                    \
+  do {                                                   \
+    hipError_t e__ = (expr);                             \
+    if (e__ != hipSuccess) return hip_fail(e__, #expr);  \
+  } while (0)
+
+static int g_blocks_per_cu = 0, g_threads = 0;
+
+static Scene *S(rtmi_scene *s) { return reinterpret_cast<Scene *>(s); }
+static const Scene *S(const rtmi_scene *s) { return reinterpret_cast<const Scene *>(s); }
+static V3 v3(const float *p) { return mk(p[0], p[1], p[2]); }
+
+static bool make_frame(const rtmi_frame *f, FrameDev *out) {
+  if (!f || f->height <= 0 || f->width <= 0 || f->spp < 0 || f->world_size <= 0 || f->rank < 0 ||
+      f->rank >= f->world_size)
+    return false;
+  FrameDev d;
+  d.height = f->height, d.width = f->width, d.spp = f->spp, d.max_depth = f->max_depth, d.post = f->post_process;
+  d.rank = f->rank, d.world = f->world_size;
+  d.tiles_x = (f->width + RTMI_TILE - 1) / RTMI_TILE;
+  d.tiles_y = (f->height + RTMI_TILE - 1) / RTMI_TILE;
+  d.n_tiles = d.tiles_x * d.tiles_y;
+  // every rank gets the same number of work items (rank 0's share); ranks that own
+  // one tile fewer carry one inert padding tile, so gathered buffers have one stride
+  d.local_tiles = (d.n_tiles + d.world - 1) / d.world;
+  d.items = (int64_t)d.local_tiles * 64;
+  *out = d;
+  return true;
+}
+
+// jump matrices, uploaded once per device
+static std::mutex g_mu;
+static std::unordered_map<int, uint32_t *> g_jump;
+static int device_jump(uint32_t **out) {
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_jump.find(dev);
+  if (it == g_jump.end()) {
+    const HostJump &J = host_jump_tables();
+    uint32_t *d = nullptr;
+    HIP_TRY(hipMalloc(&d, J.m.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(d, J.m.data(), J.m.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    it = g_jump.emplace(dev, d).first;
+  }
+  *out = it->second;
+  return RTMI_OK;
+}
+
+template <typename R>
+static int upload(Scene *s, const std::vector<R> &v, const R **out) {
+  *out = nullptr;
+  if (v.empty()) return RTMI_OK;
+  void *d = nullptr;
+  HIP_TRY(hipMalloc(&d, v.size() * sizeof(R)));
+  s->dev_allocs.push_back(d);
+  HIP_TRY(hipMemcpy(d, v.data(), v.size() * sizeof(R), hipMemcpyHostToDevice));
+  *out = reinterpret_cast<const R *>(d);
+  return RTMI_OK;
+}
+
+extern "C" {
+
+const char *rtmi_last_error(void) { return g_err.c_str(); }
+int rtmi_version(void) { return RTMI_VERSION; }
+int rtmi_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+// ------------------------------------------------------------------ scene
+rtmi_scene *rtmi_scene_create(void) { return reinterpret_cast<rtmi_scene *>(new Scene()); }
+
+static void free_device(Scene *s) {
+  for (void *p : s->dev_allocs) (void)hipFree(p);
+  s->dev_allocs.clear();
+  s->d_counters = nullptr;
+  s->committed = false;
+}
+void rtmi_scene_destroy(rtmi_scene *s) {
+  if (!s) return;
+  free_device(S(s));
+  delete S(s);
+}
+
+int rtmi_constant_texture(rtmi_scene *s, const float rgb[3]) {
+  if (!s || !rgb) return fail(RTMI_ERR_INVALID, "null argument");
+  HostTex t;
+  t.rgb = v3(rgb);
+  S(s)->texs.push_back(t);
+  return (int)S(s)->texs.size() - 1;
+}
+int rtmi_image_texture(rtmi_scene *s, const uint8_t *rgba, int height, int width, size_t pitch) {
+  if (!s || !rgba || height <= 0 || width <= 0) return fail(RTMI_ERR_INVALID, "bad image texture");
+  if (pitch == 0) pitch = (size_t)width * 4;
+  if (pitch < (size_t)width * 4) return fail(RTMI_ERR_INVALID, "pitch smaller than a row");
+  HostTex t;
+  t.image = true;
+  t.h = height, t.w = width;
+  t.rgba.resize((size_t)height * width * 4);
+  for (int y = 0; y < height; y++) memcpy(&t.rgba[(size_t)y * width * 4], rgba + (size_t)y * pitch, (size_t)width * 4);
+  S(s)->texs.push_back(std::move(t));
+  return (int)S(s)->texs.size() - 1;
+}
+static int add_mat(rtmi_scene *s, int kind, V3 rgb, float param, int tex) {
+  HostMat m;
+  m.kind = kind, m.rgb = rgb, m.param = param, m.tex = tex;
+  S(s)->mats.push_back(m);
+  return (int)S(s)->mats.size() - 1;
+}
+static bool tex_ok(rtmi_scene *s, int t) { return t >= 0 && t < (int)S(s)->texs.size(); }
+int rtmi_lambertian(rtmi_scene *s, const float rgb[3]) {
+  if (!s || !rgb) return fail(RTMI_ERR_INVALID, "null argument");
+  return add_mat(s, MAT_LAMBERTIAN, v3(rgb), 0.f, -1);
+}
+int rtmi_lambertian_tex(rtmi_scene *s, int texture) {
+  if (!s || !tex_ok(s, texture)) return fail(RTMI_ERR_INVALID, "unknown texture handle");
+  return add_mat(s, MAT_LAMBERTIAN, splat(0.f), 0.f, texture);
+}
+int rtmi_metal(rtmi_scene *s, const float rgb[3], float fuzz) {
+  if (!s || !rgb) return fail(RTMI_ERR_INVALID, "null argument");
+  return add_mat(s, MAT_METAL, v3(rgb), fuzz < 1 ? fuzz : 1, -1);  // metal.cu:10
+}
+int rtmi_dielectric(rtmi_scene *s, const float rgb[3], double refractive_index) {
+  if (!s || !rgb) return fail(RTMI_ERR_INVALID, "null argument");
+  return add_mat(s, MAT_DIELECTRIC, v3(rgb), (float)refractive_index, -1);
+}
+int rtmi_diffuse_light(rtmi_scene *s, int texture) {
+  if (!s || !tex_ok(s, texture)) return fail(RTMI_ERR_INVALID, "unknown texture handle");
+  return add_mat(s, MAT_LIGHT, splat(0.f), 0.f, texture);
+}
+
+static int append(rtmi_scene *s, const HostObj &o) {
+  if (S(s)->world.size() >= RTMI_MAX_HITABLES)
+    return fail(RTMI_ERR_CAPACITY, "HitableList::kMaxHitables (1024) exceeded");
+  S(s)->world.push_back(o);
+  S(s)->committed = false;
+  return RTMI_OK;
+}
+static bool mat_ok(rtmi_scene *s, int m) { return m >= 0 && m < (int)S(s)->mats.size(); }
+
+int rtmi_add_sphere(rtmi_scene *s, const float c[3], double radius, int material) {
+  if (!s || !c || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad sphere arguments");
+  HostObj o{};
+  o.kind = OBJ_SPHERE, o.mat = material, o.p[0] = v3(c), o.radius = radius;
+  return append(s, o);
+}
+int rtmi_add_triangle(rtmi_scene *s, const float p[9], int material) {
+  if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad triangle arguments");
+  HostObj o{};
+  o.kind = OBJ_TRI, o.mat = material;
+  for (int i = 0; i < 3; i++) o.p[i] = v3(p + 3 * i);
+  return append(s, o);
+}
+int rtmi_add_parallelogram(rtmi_scene *s, const float p[9], int material) {
+  if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelogram arguments");
+  HostObj o{};
+  o.kind = OBJ_PGRAM, o.mat = material;
+  for (int i = 0; i < 3; i++) o.p[i] = v3(p + 3 * i);
+  return append(s, o);
+}
+int rtmi_add_parallelepiped(rtmi_scene *s, const float p[12], int material) {
+  if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelepiped arguments");
+  HostObj o{};
+  o.kind = OBJ_BOX, o.mat = material;
+  V3 c[4];
+  for (int i = 0; i < 4; i++) c[i] = v3(p + 3 * i);
+  box_from_points(c, o.p);
+  return append(s, o);
+}
+int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int material, rtmi_transform_fn transform,
+                                    void *user) {
+  if (!s || !lengths || !transform || !mat_ok(s, material))
+    return fail(RTMI_ERR_INVALID, "bad parallelepiped arguments");
+  // parallelepiped.cu:37-52: axis corners from the lengths, then the user's transform
+  float p[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, q[4][3];
+  for (int i = 1; i <= 3; i++) p[i][i - 1] = lengths[i - 1];
+  for (int i = 0; i < 4; i++)
+    for (int k = 0; k < 3; k++) q[i][k] = lengths[k];
+  for (int i = 1; i <= 3; i++) q[i][i - 1] = 0;
+  HostObj o{};
+  o.kind = OBJ_BOX, o.mat = material;
+  for (int i = 0; i < 4; i++) {
+    float t[3];
+    transform(p[i], t, user);
+    o.p[i] = v3(t);
+    transform(q[i], t, user);
+    o.p[4 + i] = v3(t);
+  }
+  return append(s, o);
+}
+int rtmi_add_sky(rtmi_scene *s) {
+  if (!s) return fail(RTMI_ERR_INVALID, "null scene");
+  HostObj o{};
+  o.kind = OBJ_SKY;
+  return append(s, o);
+}
+int rtmi_add_bvh(rtmi_scene *s, const float *faces, const float *uvs, int n, int material, int leaf_max) {
+  if (!s || n < 0 || (n > 0 && !faces)) return fail(RTMI_ERR_INVALID, "bad bvh arguments");
+  if (material >= (int)S(s)->mats.size()) return fail(RTMI_ERR_INVALID, "unknown material handle");
+  HostBvh b;
+  b.n = n, b.mat = material, b.leaf_max = leaf_max > 0 ? leaf_max : 2048;
+  b.faces.assign(faces, faces + (size_t)n * 9);
+  if (uvs) b.uvs.assign(uvs, uvs + (size_t)n * 6);
+  S(s)->bvhs.push_back(std::move(b));
+  HostObj o{};
+  o.kind = OBJ_BVH, o.bvh = (int)S(s)->bvhs.size() - 1;
+  return append(s, o);
+}
+
+int rtmi_camera_pinhole(rtmi_scene *s, const float pos[3], const float look_at[3], const float up[3], double fov,
+                        double aspect) {
+  if (!s || !pos || !look_at || !up) return fail(RTMI_ERR_INVALID, "null argument");
+  camera_pinhole(*S(s), v3(pos), v3(look_at), v3(up), fov, aspect);
+  S(s)->committed = false;
+  return RTMI_OK;
+}
+int rtmi_camera_defocus(rtmi_scene *s, const float pos[3], const float look_at[3], const float up[3], double fov,
+                        double aspect, double aperture, double focus_distance) {
+  if (!s || !pos || !look_at || !up) return fail(RTMI_ERR_INVALID, "null argument");
+  camera_defocus(*S(s), v3(pos), v3(look_at), v3(up), fov, aspect, aperture, focus_distance);
+  S(s)->committed = false;
+  return RTMI_OK;
+}
+int rtmi_camera_raw(rtmi_scene *s, const float pos[3], const float llc[3], const float horiz[3], const float vert[3]) {
+  if (!s || !pos || !llc || !horiz || !vert) return fail(RTMI_ERR_INVALID, "null argument");
+  camera_raw(*S(s), v3(pos), v3(llc), v3(horiz), v3(vert));
+  S(s)->committed = false;
+  return RTMI_OK;
+}
+int rtmi_camera_get(const rtmi_scene *s, float out[21]) {
+  if (!s || !out || !S(s)->has_camera) return fail(RTMI_ERR_INVALID, "scene has no camera");
+  const CameraDev &c = S(s)->cam;
+  const V3 vs[7] = {c.position, c.llc, c.horizontal, c.vertical, c.u, c.v, S(s)->cam_w};
+  for (int i = 0; i < 7; i++) out[i * 3] = vs[i].x, out[i * 3 + 1] = vs[i].y, out[i * 3 + 2] = vs[i].z;
+  return RTMI_OK;
+}
+
+int rtmi_scene_commit(rtmi_scene *sp) {
+  if (!sp) return fail(RTMI_ERR_INVALID, "null scene");
+  Scene *s = S(sp);
+  if (rtmi_device_count() <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device: librtmi has no CPU fallback");
+  free_device(s);
+  std::string err = s->flatten();
+  if (!err.empty()) return fail(RTMI_ERR_INVALID, err);
+  HIP_TRY(hipGetDevice(&s->device));
+  // image textures
+  s->tex_recs.clear();
+  for (const HostTex &t : s->texs) {
+    if (!t.image) continue;
+    void *d = nullptr;
+    size_t pitch = 0;
+    HIP_TRY(hipMallocPitch(&d, &pitch, (size_t)t.w * 4, (size_t)t.h));
+    s->dev_allocs.push_back(d);
+    HIP_TRY(hipMemcpy2D(d, pitch, t.rgba.data(), (size_t)t.w * 4, (size_t)t.w * 4, (size_t)t.h,
+                        hipMemcpyHostToDevice));
+    TexRec r{};
+    r.rgba = reinterpret_cast<const uint8_t *>(d);
+    r.height = t.h, r.width = t.w, r.pitch = (int64_t)pitch;
+    s->tex_recs.push_back(r);
+  }
+  SceneDev d{};
+  int rc;
+  if ((rc = upload(s, s->runs, &d.runs))) return rc;
+  if ((rc = upload(s, s->spheres, &d.spheres))) return rc;
+  if ((rc = upload(s, s->pgrams, &d.pgrams))) return rc;
+  if ((rc = upload(s, s->tris, &d.tris))) return rc;
+  if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
+  if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
+  if ((rc = upload(s, s->faces, &d.faces))) return rc;
+  if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
+  if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;
+  if ((rc = upload(s, s->tex_recs, &d.texs))) return rc;
+  d.n_runs = (int)s->runs.size();
+  d.n_mats = (int)s->mat_recs.size();
+  d.cam = s->cam;
+  s->dev = d;
+  void *c = nullptr;
+  HIP_TRY(hipMalloc(&c, 2 * sizeof(unsigned long long)));
+  s->dev_allocs.push_back(c);
+  HIP_TRY(hipMemset(c, 0, 2 * sizeof(unsigned long long)));
+  s->d_counters = reinterpret_cast<unsigned long long *>(c);
+  HIP_TRY(hipDeviceSynchronize());
+  s->committed = true;
+  return RTMI_OK;
+}
+
+int rtmi_scene_stats(const rtmi_scene *sp, int64_t out[8]) {
+  if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
+  Scene tmp = *S(sp);  // flatten a copy so an uncommitted scene can be inspected
+  tmp.dev_allocs.clear();
+  std::string err = tmp.flatten();
+  if (!err.empty()) return fail(RTMI_ERR_INVALID, err);
+  out[0] = (int64_t)tmp.world.size();
+  out[1] = (int64_t)tmp.spheres.size();
+  out[2] = (int64_t)tmp.pgrams.size();
+  out[3] = (int64_t)tmp.tris.size();
+  out[4] = (int64_t)tmp.faces.size();
+  out[5] = (int64_t)tmp.nodes.size();
+  out[6] = (int64_t)tmp.mat_recs.size();
+  out[7] = (int64_t)tmp.texs.size();
+  return RTMI_OK;
+}
+
+int64_t rtmi_scene_bytes_per_ray(const rtmi_scene *sp) {
+  if (!sp) return fail(RTMI_ERR_INVALID, "null scene");
+  Scene tmp = *S(sp);
+  tmp.dev_allocs.clear();
+  std::string err = tmp.flatten();
+  if (!err.empty()) return fail(RTMI_ERR_INVALID, err);
+  return tmp.bytes_per_ray;
+}
+
+// ------------------------------------------------------------------ frame
+int64_t rtmi_frame_work_items(const rtmi_frame *f) {
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  return d.items;
+}
+int64_t rtmi_frame_pixel_of(const rtmi_frame *f, int64_t q) {
+  FrameDev d;
+  if (!make_frame(f, &d) || q < 0 || q >= d.items) return -1;
+  return frame_pixel_of(d, d.rank, q);
+}
+size_t rtmi_states_bytes(const rtmi_frame *f) {
+  FrameDev d;
+  if (!make_frame(f, &d)) return 0;
+  return (size_t)d.items * RTMI_STATE_WORDS * sizeof(uint32_t);
+}
+size_t rtmi_tiles_bytes(const rtmi_frame *f) {
+  FrameDev d;
+  if (!make_frame(f, &d)) return 0;
+  return (size_t)d.items * 3 * sizeof(float);
+}
+
+// ------------------------------------------------------------------ RNG
+int rtmi_rng_init(uint64_t seed, const rtmi_frame *f, void *d_states, void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_states) return fail(RTMI_ERR_INVALID, "bad rng_init arguments");
+  if (rtmi_device_count() <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device: librtmi has no CPU fallback");
+  uint32_t *jump = nullptr;
+  int rc = device_jump(&jump);
+  if (rc) return rc;
+  HIP_TRY(launch_rng_init(seed, d, jump, reinterpret_cast<uint32_t *>(d_states), (hipStream_t)stream));
+  return RTMI_OK;
+}
+int rtmi_rng_host_state(uint64_t seed, uint64_t subsequence, uint32_t state[RTMI_STATE_WORDS]) {
+  if (!state) return fail(RTMI_ERR_INVALID, "null state");
+  Rng r = host_rng_init(seed, subsequence);
+  state[0] = r.d, state[1] = r.v0, state[2] = r.v1, state[3] = r.v2, state[4] = r.v3, state[5] = r.v4;
+  return RTMI_OK;
+}
+float rtmi_rng_host_random_float(float mn, float mx, uint32_t state[RTMI_STATE_WORDS]) {
+  Rng r{state[0], state[1], state[2], state[3], state[4], state[5]};
+  float x = rng_range(mn, mx, r);
+  state[0] = r.d, state[1] = r.v0, state[2] = r.v1, state[3] = r.v2, state[4] = r.v3, state[5] = r.v4;
+  return x;
+}
+int rtmi_rng_set_state(const rtmi_frame *f, void *d_states, int64_t q, const uint32_t state[RTMI_STATE_WORDS],
+                       void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_states || !state || q < 0 || q >= d.items)
+    return fail(RTMI_ERR_INVALID, "bad rng_set_state arguments");
+  uint32_t *base = reinterpret_cast<uint32_t *>(d_states);
+  for (int w = 0; w < RTMI_STATE_WORDS; w++)
+    HIP_TRY(hipMemcpyAsync(base + (size_t)w * d.items + q, &state[w], sizeof(uint32_t), hipMemcpyHostToDevice,
+                           (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return RTMI_OK;
+}
+int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uint32_t state[RTMI_STATE_WORDS],
+                       void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_states || !state || q < 0 || q >= d.items)
+    return fail(RTMI_ERR_INVALID, "bad rng_get_state arguments");
+  const uint32_t *base = reinterpret_cast<const uint32_t *>(d_states);
+  for (int w = 0; w < RTMI_STATE_WORDS; w++)
+    HIP_TRY(hipMemcpyAsync(&state[w], base + (size_t)w * d.items + q, sizeof(uint32_t), hipMemcpyDeviceToHost,
+                           (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return RTMI_OK;
+}
+
+// ------------------------------------------------------------------ render
+int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float *d_tiles, uint32_t *d_ray_counts,
+                void *stream) {
+  if (!sp || !d_states || !d_tiles) return fail(RTMI_ERR_INVALID, "null argument");
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
+  int dev = 0;
+  HIP_TRY(hipGetDevice(&dev));
+  if (dev != s->device) return fail(RTMI_ERR_INVALID, "scene was committed on another device");
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  const int threads = g_threads > 0 ? g_threads : 256;
+  const uint32_t variant = pick_variant(s->features);
+  int per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : render_occupancy(variant, threads);
+  if (per_cu <= 0) per_cu = 1;
+  int64_t want = (d.items + threads - 1) / threads;
+  int64_t cap = (int64_t)prop.multiProcessorCount * per_cu;
+  int blocks = (int)(want < cap ? want : cap);
+  if (blocks < 1) blocks = 1;
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream));
+  HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
+                        s->d_counters, blocks, threads, (hipStream_t)stream));
+  return RTMI_OK;
+}
+
+int rtmi_last_ray_total(const rtmi_scene *sp, uint64_t *out_rays, void *stream) {
+  if (!sp || !out_rays) return fail(RTMI_ERR_INVALID, "null argument");
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  unsigned long long v = 0;
+  HIP_TRY(hipMemcpyAsync(&v, s->d_counters + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  *out_rays = v;
+  return RTMI_OK;
+}
+
+int rtmi_untile(const rtmi_frame *f, const float *d_all_tiles, float *d_image, void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_all_tiles || !d_image) return fail(RTMI_ERR_INVALID, "bad untile arguments");
+  HIP_TRY(launch_untile(d, d_all_tiles, d_image, (hipStream_t)stream));
+  return RTMI_OK;
+}
+int rtmi_untile_u32(const rtmi_frame *f, const uint32_t *d_all, uint32_t *d_image, void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_all || !d_image) return fail(RTMI_ERR_INVALID, "bad untile arguments");
+  HIP_TRY(launch_untile_u32(d, d_all, d_image, (hipStream_t)stream));
+  return RTMI_OK;
+}
+int rtmi_post_process(float *d_image, int64_t n_pixels, int spp, void *stream) {
+  if (!d_image || n_pixels < 0 || spp <= 0) return fail(RTMI_ERR_INVALID, "bad post_process arguments");
+  HIP_TRY(launch_post(d_image, n_pixels * 3, spp, (hipStream_t)stream));
+  return RTMI_OK;
+}
+int rtmi_get_workload(int rank, int world_size, int spp) {
+  return spp / world_size + (int)(rank < (spp % world_size));  // utils.cu:111-113
+}
+int rtmi_set_launch(int blocks_per_cu, int threads_per_block) {
+  if (blocks_per_cu < 0 || threads_per_block < 0 || (threads_per_block % 64) != 0 || threads_per_block > 256)
+    return fail(RTMI_ERR_INVALID, "threads_per_block must be a multiple of 64, at most 256");
+  g_blocks_per_cu = blocks_per_cu;
+  g_threads = threads_per_block;
+  return RTMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+// Internal launch interface between the C ABI (capi.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scene_dev.h"
+
+#define RTMI_KERNEL_MAX_DEPTH 64  // == RTMI_MAX_DEPTH of include/rtmi.h
+
+namespace rtmi {
+
+int64_t frame_pixel_of(const FrameDev &fr, int rank, int64_t q);
+
+hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_jump, uint32_t *d_states,
+                           hipStream_t stream);
+
+// Kernel specialisation covering a feature set, its occupancy, and its launch.
+uint32_t pick_variant(uint32_t features);
+int render_occupancy(uint32_t variant, int threads);
+hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
+                         uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
+                         hipStream_t stream);
+
+hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
+hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);
+hipError_t launch_post(float *d_img, int64_t n, int spp, hipStream_t stream);
+
+}  // namespace rtmi

@@ -1,0 +1,713 @@
+// HIP kernels of the trace path for gfx950 (MI355X): RNG seeding, the persistent
+// per-pixel trace loop, tile scatter and post-process.
+//
+// Shape of the trace kernel (DESIGN.md "Kernels"):
+//   * persistent lanes: a lane owns ONE pixel at a time and walks its samples
+//     serially (the cuRAND stream of a pixel is consumed in order, so samples of
+//     a pixel cannot be spread over lanes without changing the image); when a
+//     path ends the lane immediately regenerates the next camera ray, when the
+//     pixel ends it pulls the next work item from a global queue
+//     (wave-aggregated atomic), so every lane of a wave enters the intersection
+//     loop on every iteration;
+//   * closest hit walks the world list in list order with wave-uniform control
+//     flow: every lane tests the same primitive, whose record arrives in SGPRs
+//     through scalar loads (s_load_dwordx8/x16, scalar cache) — no per-lane
+//     geometry traffic at all for list scenes;
+//   * acceptance bookkeeping in the loop is 3 VGPRs (ok, t_to, winner id); the
+//     winner's normal / material are resolved once per ray after the loop;
+//   * the material table is staged in LDS once per workgroup;
+//   * arithmetic follows the reference operation by operation (binary32 with
+//     the binary64 islands of sphere.cu / ray_tracing.cu:68-73); the file is
+//     compiled with -ffp-contract=off and IEEE divide/sqrt.
+//
+// Reference functions restated here (paths relative to
+// /root/reference/ray-tracing-cuda/): PathTracing + Trace ray_tracing.cu:12-85,
+// Camera::RayAt camera.cu:57-77, HitableList::Hit hitable_list.cu:7-25,
+// Sphere::Hit sphere.cu:11-64, TriangleHit utils.cu:49-85, Parallelogram::Hit
+// parallelogram.cu:17-44, Sky sky.cu:9-27, AABB::Hit bvh.cu:6-30, BVHNode::Hit
+// bvh.cuh:123-158, Lambertian lambertian.cu:19-43, Metal metal.cu:12-36,
+// Dielectric dielectric.cu:16-44, DiffuseLight diffuse_light.cu:5-13,
+// ImageTexture::Value textures/image_texture.cu:9-15, CudaRandomInit utils.cu:43-47.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "scene_dev.h"
+#include "vec.h"
+#include "xorwow.h"
+
+namespace rtmi {
+
+// ------------------------------------------------------------------ frame math
+__host__ __device__ __forceinline__ int64_t frame_pixel_of_rank(const FrameDev &fr, int rank, int64_t q) {
+  int64_t lt = q >> 6;
+  int w = (int)(q & 63);
+  int64_t gt = lt * fr.world + rank;
+  if (gt >= fr.n_tiles) return -1;
+  int ty = (int)(gt / fr.tiles_x), tx = (int)(gt % fr.tiles_x);
+  int i = ty * 8 + (w >> 3), j = tx * 8 + (w & 7);
+  if (i >= fr.height || j >= fr.width) return -1;
+  return (int64_t)i * fr.width + j;
+}
+
+int64_t frame_pixel_of(const FrameDev &fr, int rank, int64_t q) { return frame_pixel_of_rank(fr, rank, q); }
+
+// ------------------------------------------------------------------ RNG init
+// state(q) = seed scramble, then v <- A^(idx * 2^67) v, idx = global pixel index.
+// The jump matrix for bit k is wave-uniform -> scalar loads; lanes whose bit is
+// clear keep their vector.
+__global__ __launch_bounds__(256) void rng_init_kernel(uint64_t seed, FrameDev fr,
+                                                        const uint32_t *__restrict__ jump,
+                                                        uint32_t *__restrict__ states) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= fr.items) return;
+  int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
+  uint64_t sub = idx < 0 ? 0 : (uint64_t)idx;
+  Rng s = rng_seed(seed);
+  uint32_t v0 = s.v0, v1 = s.v1, v2 = s.v2, v3 = s.v3, v4 = s.v4;
+  for (int k = 0; k < kJumpBits; k++) {
+    if (!__any((sub >> k) != 0)) break;
+    bool bit = (sub >> k) & 1;
+    if (!__any(bit)) continue;
+    const uint32_t *M = jump + (size_t)k * kJumpWords;
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+#pragma unroll 1
+    for (int w = 0; w < 5; w++) {
+      uint32_t word = w == 0 ? v0 : w == 1 ? v1 : w == 2 ? v2 : w == 3 ? v3 : v4;
+#pragma unroll 4
+      for (int b = 0; b < 32; b++) {
+        uint32_t m = 0u - ((word >> b) & 1u);
+        const uint32_t *row = M + (w * 32 + b) * 5;
+        r0 ^= row[0] & m;
+        r1 ^= row[1] & m;
+        r2 ^= row[2] & m;
+        r3 ^= row[3] & m;
+        r4 ^= row[4] & m;
+      }
+    }
+    if (bit) {
+      v0 = r0, v1 = r1, v2 = r2, v3 = r3, v4 = r4;
+    }
+  }
+  const int64_t n = fr.items;
+  states[0 * n + q] = s.d;
+  states[1 * n + q] = v0;
+  states[2 * n + q] = v1;
+  states[3 * n + q] = v2;
+  states[4 * n + q] = v3;
+  states[5 * n + q] = v4;
+}
+
+// ------------------------------------------------------------------ trace helpers
+template <bool DT>
+struct TSel {
+  typedef float type;
+};
+template <>
+struct TSel<true> {
+  typedef double type;
+};
+
+// Winner id: kind in the top 3 bits, index below; bit 28 marks the second
+// triangle of a parallelogram.
+constexpr uint32_t ID_NONE = 0xffffffffu;
+constexpr uint32_t ID_SECOND = 1u << 28;
+constexpr uint32_t ID_INDEX_MASK = (1u << 28) - 1;
+__device__ __forceinline__ uint32_t make_id(int kind, int index) { return ((uint32_t)kind << 29) | (uint32_t)index; }
+
+// The smallest binary32 >= 1e-3 is 0.001f (it rounds up), so for a binary32 t the
+// reference's double compare `1e-3 <= t` is `0.001f <= t`; likewise
+// `fabs(det) < 1e-7` is `fabsf(det) < 1e-7f` because 1e-7f rounds up.
+// (tests/test_host_logic.py::test_float_thresholds pins both facts.)
+#define T_FROM_F 0.001f
+#define DET_EPS_F 1e-7f
+
+// utils.cu:49-85 with the ray-independent terms precomputed.
+template <typename T>
+__device__ __forceinline__ bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to, float &t, float &u, float &v) {
+  V3 pvec = cross3(d, e2);
+  float det = dot3(e1, pvec);
+  if (fabsf(det) < DET_EPS_F) return false;
+  float inv = 1.0f / det;
+  V3 tvec = o - p0;
+  u = dot3(tvec, pvec) * inv;
+  if (u < 0.0f || u > 1.0f) return false;
+  V3 qvec = cross3(tvec, e1);
+  v = dot3(d, qvec) * inv;
+  if (v < 0.0f || u + v > 1.0f) return false;
+  t = dot3(e2, qvec) * inv;
+  if (!(T_FROM_F <= t && (T)t <= t_to)) return false;
+  return true;
+}
+template <typename T>
+__device__ __forceinline__ bool tri_test(const TriRec &r, V3 o, V3 d, T t_to, float &t, float &u, float &v) {
+  return tri_test<T>(mk(r.p0[0], r.p0[1], r.p0[2]), mk(r.e1[0], r.e1[1], r.e1[2]), mk(r.e2[0], r.e2[1], r.e2[2]), o,
+                     d, t_to, t, u, v);
+}
+
+// bvh.cu:6-30 — "the segment crosses the box surface"; a box that wholly
+// contains [t_from, t_to] reports false (quirk g8).
+template <typename T>
+__device__ __forceinline__ bool aabb_test(const BvhNode &nd, V3 o, V3 d, T t_to) {
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    if (dd[i] == 0.f) continue;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      float plane = s == 0 ? nd.mn[i] : nd.mx[i];
+      float tf = (plane - oo[i]) / dd[i];
+      if (!(fabsf(tf) < INFINITY)) continue;  // isnan || isinf
+      if (!(T_FROM_F <= tf && (T)tf <= t_to)) continue;
+      bool inside = true;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        if (a == i) continue;
+        float pa = oo[a] + tf * dd[a];
+        if (!(nd.mn[a] <= pa && pa <= nd.mx[a])) inside = false;
+      }
+      if (inside) return true;
+    }
+  }
+  return false;
+}
+
+__device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) {
+  float fu = u - floorf(u), fv = v - floorf(v);
+  int ix = (int)floorf(fu * (float)tx.width);
+  int iy = (int)floorf(fv * (float)tx.height);
+  ix = ix > tx.width - 1 ? tx.width - 1 : ix;
+  iy = iy > tx.height - 1 ? tx.height - 1 : iy;
+  ix = ix < 0 ? 0 : ix;
+  iy = iy < 0 ? 0 : iy;
+  const uint8_t *px = tx.rgba + (size_t)iy * tx.pitch + (size_t)ix * 4;
+  return mk((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+}
+
+// lambertian.cu:19-31 / metal.cu:27-36: rejection-sample the unit ball.
+// l = (float)pow((double)(x*x+y*y+z*z), 0.5) == sqrtf(sum) (double rounding of
+// a square root of a binary32 value is innocuous).
+__device__ __forceinline__ V3 ball_sample(Rng &rng, float &l) {
+  float x, y, z;
+  do {
+    x = rng_range(-1.f, 1.f, rng);
+    y = rng_range(-1.f, 1.f, rng);
+    z = rng_range(-1.f, 1.f, rng);
+    l = sqrtf(x * x + y * y + z * z);
+  } while (l > 1.f);
+  return mk(x, y, z);
+}
+
+struct Hit {
+  bool ok;
+  float t;        // float(record.t)
+  uint32_t win;   // winner id
+  int32_t aux;    // BVH record index of the winner
+  float u, v;     // raw barycentrics of the winning triangle
+};
+
+// ================================================================== closest hit
+// HitableList::Hit (hitable_list.cu:7-25) over the flattened world.  A nested
+// Parallelepiped list is equivalent to its six parallelograms inlined at its
+// position (DESIGN.md "List flattening").
+template <uint32_t F>
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
+  constexpr bool DT = (F & F_SPHERE) != 0;
+  typedef typename TSel<DT>::type T;
+  bool ok = false;
+  T t_to = (T)INFINITY;
+  uint32_t win = ID_NONE;
+  int32_t aux = 0;
+  float bu = 0.f, bv = 0.f;
+
+  double sa = 0.0, sa2 = 0.0;
+  if (F & F_SPHERE) {
+    float la = len3(d);       // sphere.cu:13: pow(length(dir), 2) in float, then widened
+    sa = (double)(la * la);
+    sa2 = 2 * sa;
+  }
+
+  for (int ri = 0; ri < sc.n_runs; ri++) {
+    const Run run = sc.runs[ri];
+    if (run.kind == RUN_SKY) {
+      // sky.cu:18-27: t = 1e9; t_from <= 1e9 always holds
+      const T ts = (T)1e9f;
+      bool hit = ts <= t_to;
+      bool acc = hit && (!ok || ts < t_to);
+      ok = ok || acc;
+      t_to = acc ? ts : t_to;
+      win = acc ? make_id(RUN_SKY, 0) : win;
+    }
+    if ((F & F_PGRAM) && run.kind == RUN_PGRAM) {
+      for (int i = 0; i < run.count; i++) {
+        const PgramRec &pg = sc.pgrams[run.first + i];
+        float t = 0.f, u = 0.f, v = 0.f;
+        uint32_t id = make_id(RUN_PGRAM, run.first + i);
+        bool hit = tri_test<T>(pg.a, o, d, t_to, t, u, v);
+        if (!hit) {  // parallelogram.cu:33: second triangle only when the first missed
+          hit = tri_test<T>(pg.b, o, d, t_to, t, u, v);
+          id |= ID_SECOND;
+        }
+        bool acc = hit && (!ok || (T)t < t_to);
+        ok = ok || acc;
+        t_to = acc ? (T)t : t_to;
+        win = acc ? id : win;
+        if (F & F_TEX) {
+          bu = acc ? u : bu;
+          bv = acc ? v : bv;
+        }
+      }
+    }
+    if ((F & F_SPHERE) && run.kind == RUN_SPHERE) {
+      for (int i = 0; i < run.count; i++) {
+        const SphereRec &sr = sc.spheres[run.first + i];
+        V3 oc = o - mk(sr.cx, sr.cy, sr.cz);
+        double b = (double)(2.0f * dot3(d, oc));
+        float lc = len3(oc);
+        double c = (double)(lc * lc) - sr.r2;
+        double disc = b * b - 4 * sa * c;
+        bool hit = false;
+        double t = 0.0;
+        if (!(disc < 0)) {
+          double sq = sqrt(disc);
+          t = (-b - sq) / sa2;
+          hit = (1e-3 <= t && t <= (double)t_to);
+          if (!hit) {
+            t = (-b + sq) / sa2;
+            hit = (1e-3 <= t && t <= (double)t_to);
+          }
+        }
+        bool acc = hit && (!ok || t < (double)t_to);
+        ok = ok || acc;
+        t_to = acc ? (T)t : t_to;
+        win = acc ? make_id(RUN_SPHERE, run.first + i) : win;
+      }
+    }
+    if ((F & F_TRI) && run.kind == RUN_TRI) {
+      for (int i = 0; i < run.count; i++) {
+        const TriangleRec &tr = sc.tris[run.first + i];
+        float t = 0.f, u = 0.f, v = 0.f;
+        bool hit = tri_test<T>(tr.a, o, d, t_to, t, u, v);
+        bool acc = hit && (!ok || (T)t < t_to);
+        ok = ok || acc;
+        t_to = acc ? (T)t : t_to;
+        win = acc ? make_id(RUN_TRI, run.first + i) : win;
+        if (F & F_TEX) {
+          bu = acc ? u : bu;
+          bv = acc ? v : bv;
+        }
+      }
+    }
+    if ((F & F_BVH) && run.kind == RUN_BVH) {
+      for (int i = 0; i < run.count; i++) {
+        const BvhRec br = sc.bvhs[run.first + i];
+        // bvh.cuh:123-158 as an explicit depth-first walk: the left subtree first,
+        // then the right child's box is tested against the t_to the left subtree
+        // left behind; any accepted face (t <= t_to, inclusive) replaces the record.
+        // The root's own box is never tested (bvh.cuh:175-177).
+        int stack[40];
+        int top = 0;
+        stack[top++] = br.root;
+        bool first = true;
+        T bt_to = t_to;
+        bool bhit = false;
+        int bface = 0;
+        float fu = 0.f, fv = 0.f;
+        while (top > 0) {
+          int ni = stack[--top];
+          const BvhNode nd = sc.nodes[ni];
+          if (!first && !aabb_test<T>(nd, o, d, bt_to)) continue;
+          first = false;
+          if (nd.right < 0) {
+            int cnt = -nd.right;
+            for (int fi = 0; fi < cnt; fi++) {
+              const FaceRec &fc = sc.faces[nd.left + fi];
+              float t = 0.f, u = 0.f, v = 0.f;
+              if (tri_test<T>(mk(fc.p0[0], fc.p0[1], fc.p0[2]), mk(fc.e1[0], fc.e1[1], fc.e1[2]),
+                              mk(fc.e2[0], fc.e2[1], fc.e2[2]), o, d, bt_to, t, u, v)) {
+                bt_to = (T)t;
+                bhit = true;
+                bface = nd.left + fi;
+                fu = u, fv = v;
+              }
+            }
+          } else {
+            stack[top++] = nd.right;
+            stack[top++] = nd.left;
+          }
+        }
+        bool acc = bhit && (!ok || bt_to < t_to);
+        ok = ok || acc;
+        t_to = acc ? bt_to : t_to;
+        win = acc ? make_id(RUN_BVH, bface) : win;
+        aux = acc ? run.first + i : aux;
+        bu = acc ? fu : bu;
+        bv = acc ? fv : bv;
+      }
+    }
+  }
+  Hit h;
+  h.ok = ok;
+  h.t = (float)t_to;
+  h.win = win;
+  h.aux = aux;
+  h.u = bu;
+  h.v = bv;
+  return h;
+}
+
+// ================================================================== trace kernel
+template <uint32_t F>
+__global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, uint32_t *__restrict__ states,
+                                                      float *__restrict__ out, uint32_t *__restrict__ ray_counts,
+                                                      unsigned long long *__restrict__ counters) {
+  __shared__ MatRec s_mats[kLdsMats];
+  const bool mats_in_lds = sc.n_mats <= kLdsMats;
+  if (mats_in_lds) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_mats);
+    for (int w = threadIdx.x; w < sc.n_mats * 8; w += blockDim.x) dst[w] = src[w];
+  }
+  __syncthreads();
+
+  const int64_t n_items = fr.items;
+  // per-lane pixel state
+  int64_t q = 0;
+  int pi = 0, pj = 0, k = 0;
+  bool has_px = false, done = false, active = false;
+  V3 color = splat(0.f);
+  uint32_t rays = 0;
+  unsigned long long ray_total = 0;
+  Rng rng = {0, 0, 0, 0, 0, 0};
+  // per-lane path state
+  V3 o = splat(0.f), d = splat(0.f);
+  int depth = 0;
+  // Layer::attenuation stack (ray_tracing.cuh:9-15).  Layer::emitted is 0 for every
+  // material that scatters (only DiffuseLight and Sky emit, and neither scatters).
+  float att[RTMI_KERNEL_MAX_DEPTH * 3];
+
+  for (;;) {
+    // -------------------------------------------------------- sample / pixel bookkeeping
+    if (!active && !done) {
+      if (has_px && k >= fr.spp) {
+        V3 c = color;
+        if (fr.post) {  // ray_tracing.cu:78-83
+          c = c / (float)fr.spp;
+          c = mk(clamp1(c.x, 0.f, 1.f), clamp1(c.y, 0.f, 1.f), clamp1(c.z, 0.f, 1.f));
+          c = mk(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
+        }
+        out[q * 3 + 0] = c.x;
+        out[q * 3 + 1] = c.y;
+        out[q * 3 + 2] = c.z;
+        if (ray_counts) ray_counts[q] = rays;
+        ray_total += rays;
+        states[0 * n_items + q] = rng.d;
+        states[1 * n_items + q] = rng.v0;
+        states[2 * n_items + q] = rng.v1;
+        states[3 * n_items + q] = rng.v2;
+        states[4 * n_items + q] = rng.v3;
+        states[5 * n_items + q] = rng.v4;
+        has_px = false;
+      }
+      while (!has_px && !done) {
+        unsigned long long nq = atomicAdd(&counters[0], 1ull);
+        if ((int64_t)nq >= n_items) {
+          done = true;
+          break;
+        }
+        q = (int64_t)nq;
+        int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
+        if (idx < 0 || fr.spp <= 0) {  // ragged-tile padding (or nothing to sample)
+          out[q * 3 + 0] = 0.f, out[q * 3 + 1] = 0.f, out[q * 3 + 2] = 0.f;
+          if (ray_counts) ray_counts[q] = 0;
+          continue;
+        }
+        pi = (int)(idx / fr.width);
+        pj = (int)(idx % fr.width);
+        rng.d = states[0 * n_items + q];
+        rng.v0 = states[1 * n_items + q];
+        rng.v1 = states[2 * n_items + q];
+        rng.v2 = states[3 * n_items + q];
+        rng.v3 = states[4 * n_items + q];
+        rng.v4 = states[5 * n_items + q];
+        k = 0;
+        rays = 0;
+        color = splat(0.f);
+        has_px = true;
+      }
+      if (has_px) {
+        // ray_tracing.cu:68-74 + camera.cu:57-70
+        float r1 = rng_range(0.f, 1.f, rng);
+        float r2 = rng_range(0.f, 1.f, rng);
+        double x = ((double)r1 + (double)pj) / (double)fr.width;
+        double y = ((double)r2 + (double)(fr.height - pi)) / (double)fr.height;
+        x = 2 * x - 1;
+        y = 2 * y - 1;
+        x = (x + 1) / 2;
+        y = (y + 1) / 2;
+        V3 target = sc.cam.llc + (float)x * sc.cam.horizontal + (float)y * sc.cam.vertical;
+        V3 origin = sc.cam.position;
+        if (F & F_DEFOCUS) {
+          if (sc.cam.defocus) {  // camera.cu:63-65,74-77 (a square, drawn left to right)
+            float ox = rng_range(0.f, sc.cam.lens_radius, rng);
+            float oy = rng_range(0.f, sc.cam.lens_radius, rng);
+            origin = sc.cam.position + sc.cam.u * ox + sc.cam.v * oy;
+          }
+        }
+        o = origin;
+        d = unit3(unit3(target - origin));  // RayAt normalises, Ray's constructor normalises again
+        k++;
+        depth = 0;
+        active = true;
+      }
+    }
+    if (!__any(active)) break;
+
+    if (active) {
+      Hit h = closest_hit<F>(sc, o, d);
+      rays++;
+
+      V3 result = splat(0.f);
+      bool ended = true;
+      if (h.ok && depth < fr.max_depth) {  // ray_tracing.cu:23
+        const uint32_t kind = h.win >> 29;
+        const uint32_t index = h.win & ID_INDEX_MASK;
+        V3 p = o + h.t * d;  // ray_tracing.cu:32 and the materials' own `p`
+        if (kind == RUN_SKY) {
+          // sky.cu:9-14: Scatter false; Emit(p) = gradient on normalize(p)
+          V3 dir = unit3(p);
+          float tg = (float)(0.5 * ((double)dir.y + 1.0));
+          float w0 = 1.0f - tg;
+          result = mk(w0 * 1.0f + tg * 0.5f, w0 * 1.0f + tg * 0.7f, w0 * 1.0f + tg * 1.0f);
+        } else {
+          V3 nrm = splat(0.f);
+          int mat = 0;
+          float tu = 0.f, tv = 0.f;  // record.u, record.v (only read by image textures)
+          if ((F & F_PGRAM) && kind == RUN_PGRAM) {
+            const PgramRec &pg = sc.pgrams[index];
+            const bool second = (h.win & ID_SECOND) != 0;
+            const float *nn = second ? pg.b.n : pg.a.n;
+            V3 n = mk(nn[0], nn[1], nn[2]);
+            nrm = dot3(d, n) < 0.f ? n : -n;  // utils.cu:80
+            mat = pg.mat;
+            if (F & F_TEX) {  // parallelogram.cu:26-29,35-38
+              float w = (float)((1.0 - (double)h.u) - (double)h.v);
+              if (!second) {
+                tu = (0.f * w + 1.f * h.u) + 0.f * h.v;
+                tv = (1.f * w + 1.f * h.u) + 0.f * h.v;
+              } else {
+                tu = (1.f * w + 0.f * h.u) + 1.f * h.v;
+                tv = (1.f * w + 0.f * h.u) + 0.f * h.v;
+              }
+            }
+          }
+          if ((F & F_TRI) && kind == RUN_TRI) {
+            const TriangleRec &tr = sc.tris[index];
+            V3 n = mk(tr.a.n[0], tr.a.n[1], tr.a.n[2]);
+            nrm = dot3(d, n) < 0.f ? n : -n;
+            mat = tr.mat;
+            tu = h.u, tv = h.v;  // triangle.cu:13
+          }
+          if ((F & F_SPHERE) && kind == RUN_SPHERE) {
+            const SphereRec &sr = sc.spheres[index];
+            nrm = unit3(p - mk(sr.cx, sr.cy, sr.cz));  // sphere.cu:25-26
+            mat = sr.mat;
+            if (F & F_TEX) {  // sphere.cu:60-63
+              const float pi_f = 3.14159265358979323846264338327950288f;
+              float theta = acosf(-nrm.y);
+              float phi = atan2f(-nrm.z, nrm.x) + pi_f;
+              tu = phi / (2 * pi_f);
+              tv = theta / pi_f;
+            }
+          }
+          if ((F & F_BVH) && kind == RUN_BVH) {
+            const FaceRec &fc = sc.faces[index];
+            V3 n = mk(fc.n[0], fc.n[1], fc.n[2]);
+            nrm = dot3(d, n) < 0.f ? n : -n;
+            const BvhRec br = sc.bvhs[h.aux];
+            mat = br.mat;
+            if ((F & F_TEX) && br.has_uv) {  // bvh.cuh:41-45
+              const float *tc = sc.face_uv + (size_t)index * 6;
+              float w = (float)((1.0 - (double)h.u) - (double)h.v);
+              tu = (tc[0] * w + tc[2] * h.u) + tc[4] * h.v;
+              tv = (tc[1] * w + tc[3] * h.u) + tc[5] * h.v;
+            }
+          }
+          const MatRec m = mats_in_lds ? s_mats[mat] : sc.mats[mat];
+          V3 rgb = mk(m.r, m.g, m.b);
+          if (F & F_TEX) {
+            if (m.tex >= 0 && (m.kind == MAT_LAMBERTIAN || m.kind == MAT_LIGHT)) {
+              // image_texture.cu:11-13: v = 1.0 - v in double, then float coordinates
+              rgb = tex_sample(sc.texs[m.tex], tu, (float)(1.0 - (double)tv));
+            }
+          }
+          if (m.kind == MAT_LIGHT) {
+            result = rgb;  // diffuse_light.cu:5-13
+          } else {
+            const float dn = dot3(d, nrm);
+            V3 nd = splat(0.f);
+            bool scattered = false;
+            if (m.kind == MAT_LAMBERTIAN) {  // lambertian.cu:33-43
+              if (!(dn >= 0.f)) {
+                float l;
+                V3 s = ball_sample(rng, l);
+                s = mk(s.x / l, s.y / l, s.z / l);
+                nd = unit3(s + nrm);
+                scattered = true;
+              }
+            } else if (m.kind == MAT_METAL) {  // metal.cu:12-25
+              if (!(dn >= 0.f)) {
+                V3 refl = reflect3(d, nrm);
+                if (m.param > 0.f) {
+                  float l;
+                  V3 s = ball_sample(rng, l);
+                  nd = refl + m.param * s;
+                } else {
+                  nd = refl;
+                }
+                scattered = true;
+              }
+            } else {  // MAT_DIELECTRIC, dielectric.cu:16-44
+              if (dn >= 0.f)
+                nd = refract3(d, -nrm, m.param / 1.0f);
+              else
+                nd = refract3(d, nrm, 1.0f / m.param);
+              bool zero = (nd.x == 0.f && nd.y == 0.f && nd.z == 0.f);
+              bool nan = (nd.x != nd.x) || (nd.y != nd.y) || (nd.z != nd.z);
+              scattered = !(zero || nan);
+            }
+            if (scattered) {
+              att[depth * 3 + 0] = rgb.x;
+              att[depth * 3 + 1] = rgb.y;
+              att[depth * 3 + 2] = rgb.z;
+              depth++;
+              o = p;
+              d = unit3(nd);  // Ray's constructor
+              ended = false;
+            }
+          }
+        }
+      }
+      if (ended) {
+        // ray_tracing.cu:50-52 with emitted == 0 on every stored layer
+        for (int i = depth - 1; i >= 0; i--) {
+          result = mk(0.f + att[i * 3 + 0] * result.x, 0.f + att[i * 3 + 1] * result.y,
+                      0.f + att[i * 3 + 2] * result.z);
+        }
+        color = color + result;
+        active = false;
+      }
+    }
+  }
+
+  // total closest-hit queries: wave reduce, one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) ray_total += __shfl_down(ray_total, off);
+  if ((threadIdx.x & 63) == 0 && ray_total) atomicAdd(&counters[1], ray_total);
+}
+
+// ------------------------------------------------------------------ untile / post
+template <typename E, int C>
+__global__ __launch_bounds__(256) void untile_kernel(FrameDev fr, const E *__restrict__ tiles, E *__restrict__ image) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t total = fr.items * fr.world;
+  if (g >= total) return;
+  int rank = (int)(g / fr.items);
+  int64_t q = g % fr.items;
+  int64_t idx = frame_pixel_of_rank(fr, rank, q);
+  if (idx < 0) return;
+#pragma unroll
+  for (int c = 0; c < C; c++) image[idx * C + c] = tiles[g * C + c];
+}
+
+__global__ __launch_bounds__(256) void post_kernel(float *__restrict__ img, int64_t n, int spp) {
+  int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  img[g] = sqrtf(clamp1(img[g] / (float)spp, 0.f, 1.f));  // utils.cu:127-128
+}
+
+// ------------------------------------------------------------------ launchers
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_jump, uint32_t *d_states,
+                           hipStream_t stream) {
+  if (fr.items == 0) return hipSuccess;
+  hipLaunchKernelGGL(rng_init_kernel, dim3((unsigned)cdiv(fr.items, 256)), dim3(256), 0, stream, seed, fr, d_jump,
+                     d_states);
+  return hipGetLastError();
+}
+
+template <uint32_t F>
+static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
+                                  uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
+                                  hipStream_t stream) {
+  hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), 0, stream, sc, fr, d_states, d_out, d_ray_counts,
+                     d_counters);
+  return hipGetLastError();
+}
+
+template <uint32_t F>
+static int occupancy_t(int threads) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<F>, threads, 0) != hipSuccess) nb = 0;
+  return nb;
+}
+
+// The specialisations that are instantiated; features outside them fall back to F_ALL.
+#define RTMI_FOR_EACH_VARIANT(X)                     \
+  X(0u)                                              \
+  X(F_PGRAM)                                         \
+  X(F_SPHERE)                                        \
+  X(F_PGRAM | F_BVH)                                 \
+  X(F_PGRAM | F_SPHERE | F_TEX)                      \
+  X(F_ALL)
+
+uint32_t pick_variant(uint32_t features) {
+#define X(V) \
+  if ((features & ~(uint32_t)(V)) == 0) return (V);
+  RTMI_FOR_EACH_VARIANT(X)
+#undef X
+  return F_ALL;
+}
+
+int render_occupancy(uint32_t variant, int threads) {
+#define X(V) \
+  if (variant == (uint32_t)(V)) return occupancy_t<(V)>(threads);
+  RTMI_FOR_EACH_VARIANT(X)
+#undef X
+  return 0;
+}
+
+hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
+                         uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
+                         hipStream_t stream) {
+#define X(V) \
+  if (variant == (uint32_t)(V)) \
+    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, blocks, threads, stream);
+  RTMI_FOR_EACH_VARIANT(X)
+#undef X
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream) {
+  int64_t total = fr.items * fr.world;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL((untile_kernel<float, 3>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, fr, d_tiles,
+                     d_image);
+  return hipGetLastError();
+}
+
+hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream) {
+  int64_t total = fr.items * fr.world;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL((untile_kernel<uint32_t, 1>), dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, fr,
+                     d_tiles, d_image);
+  return hipGetLastError();
+}
+
+hipError_t launch_post(float *d_img, int64_t n, int spp, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(post_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, d_img, n, spp);
+  return hipGetLastError();
+}
+
+}  // namespace rtmi

@@ -1,0 +1,86 @@
+// Host-side scene recorder: the reference's constructors (Sphere, Parallelogram,
+// Parallelepiped, BVH, Lambertian, ... and Camera) as plain records, plus the
+// flatten pass that turns the recorded world list into the device layout of
+// scene_dev.h.  Constructor arithmetic that the reference performs at scene build
+// time (parallelogram 4th corner, parallelepiped corners, camera frame, BVH
+// bounds/sort/split) is done here, on the host, with the same binary32 operations.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "scene_dev.h"
+#include "vec.h"
+
+namespace rtmi {
+
+struct HostTex {
+  bool image = false;
+  V3 rgb{0, 0, 0};
+  std::vector<uint8_t> rgba;  // tightly packed
+  int h = 0, w = 0;
+};
+
+struct HostMat {
+  int32_t kind = MAT_LAMBERTIAN;
+  V3 rgb{0, 0, 0};
+  float param = 0.f;
+  int tex = -1;  // texture handle (Lambertian(Texture*) / DiffuseLight(Texture*))
+};
+
+enum ObjKind { OBJ_SPHERE, OBJ_TRI, OBJ_PGRAM, OBJ_BOX, OBJ_SKY, OBJ_BVH };
+
+struct HostObj {
+  ObjKind kind;
+  int mat = -1;
+  V3 p[8];            // sphere: p[0]=centre; tri/pgram: p[0..2]; box: corner sets p[0..3], q = p[4..7]
+  double radius = 0;  // sphere
+  int bvh = -1;       // index into Scene::bvhs
+};
+
+struct HostBvh {
+  std::vector<float> faces;  // n*9
+  std::vector<float> uvs;    // n*6 or empty
+  int n = 0, mat = -1, leaf_max = 2048;
+};
+
+struct Scene {
+  std::vector<HostTex> texs;
+  std::vector<HostMat> mats;
+  std::vector<HostObj> world;  // HitableList order
+  std::vector<HostBvh> bvhs;
+  CameraDev cam{};
+  V3 cam_w{0, 0, 0};
+  bool has_camera = false;
+
+  // ---- flattened (valid after commit)
+  bool committed = false;
+  uint32_t features = 0;
+  std::vector<Run> runs;
+  std::vector<SphereRec> spheres;
+  std::vector<PgramRec> pgrams;
+  std::vector<TriangleRec> tris;
+  std::vector<BvhRec> bvh_recs;
+  std::vector<BvhNode> nodes;
+  std::vector<FaceRec> faces;
+  std::vector<float> face_uv;
+  std::vector<MatRec> mat_recs;
+  std::vector<TexRec> tex_recs;
+  std::vector<void *> dev_allocs;
+  SceneDev dev{};
+  unsigned long long *d_counters = nullptr;  // [0] work queue head, [1] total rays
+  int device = -1;
+  int64_t bytes_per_ray = 0;
+
+  // host-only flatten (no HIP calls); returns "" or an error message
+  std::string flatten();
+};
+
+TriRec make_tri(V3 p0, V3 p1, V3 p2);
+void camera_pinhole(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspect);
+void camera_defocus(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspect, double aperture, double focus);
+void camera_raw(Scene &s, V3 pos, V3 llc, V3 horiz, V3 vert);
+void box_from_points(const V3 p[4], V3 out[8]);
+
+}  // namespace rtmi

@@ -1,0 +1,272 @@
+// Host-side scene recorder + flatten (see scene.h).  No device code here; the
+// file is a .hip unit only so it shares vec.h's host/device helpers and the
+// -ffp-contract=off build flags with the kernels.
+#include "scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace rtmi {
+
+// utils.cu:54-55,79: v0v1, v0v2 and normalize(cross(v0v1, v0v2)) do not depend on the ray.
+TriRec make_tri(V3 p0, V3 p1, V3 p2) {
+  V3 e1 = p1 - p0, e2 = p2 - p0;
+  V3 n = unit3(cross3(e1, e2));
+  TriRec r;
+  r.p0[0] = p0.x, r.p0[1] = p0.y, r.p0[2] = p0.z;
+  r.e1[0] = e1.x, r.e1[1] = e1.y, r.e1[2] = e1.z;
+  r.e2[0] = e2.x, r.e2[1] = e2.y, r.e2[2] = e2.z;
+  r.n[0] = n.x, r.n[1] = n.y, r.n[2] = n.z;
+  return r;
+}
+
+// parallelogram.cu:10-15 + the two triangles of parallelogram.cu:25,33
+static PgramRec make_pgram(V3 p0, V3 p1, V3 p2, int mat) {
+  V3 p3 = p1 + p2 - p0;
+  PgramRec r{};
+  r.a = make_tri(p0, p1, p2);
+  r.b = make_tri(p1, p2, p3);
+  r.mat = mat;
+  return r;
+}
+
+// parallelepiped.cu:8-18: derive the four opposite corners.
+void box_from_points(const V3 p[4], V3 out[8]) {
+  auto fourth = [](V3 a, V3 b, V3 c) { return c + b - a; };
+  V3 q[4];
+  q[3] = fourth(p[0], p[1], p[2]);
+  q[2] = fourth(p[0], p[1], p[3]);
+  q[1] = fourth(p[0], p[2], p[3]);
+  q[0] = fourth(p[1], q[2], q[3]);
+  for (int i = 0; i < 4; i++) out[i] = p[i], out[4 + i] = q[i];
+}
+
+// camera.cu:24-38
+void camera_pinhole(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspect) {
+  CameraDev &c = s.cam;
+  c.defocus = 0;
+  c.lens_radius = -1.f;
+  c.position = pos;
+  V3 w = unit3(pos - look_at);
+  c.u = unit3(cross3(up, w));
+  c.v = unit3(cross3(w, c.u));
+  double half_height = std::tan(fov / 2);
+  double half_width = aspect * half_height;
+  c.horizontal = c.u * static_cast<float>(2 * half_width);
+  c.vertical = c.v * static_cast<float>(2 * half_height);
+  c.llc = pos - w - c.u * static_cast<float>(half_width) - c.v * static_cast<float>(half_height);
+  s.cam_w = w;
+  s.has_camera = true;
+}
+
+// camera.cu:6-22
+void camera_defocus(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspect, double aperture, double focus) {
+  CameraDev &c = s.cam;
+  c.defocus = 1;
+  c.position = pos;
+  V3 w = unit3(pos - look_at);
+  c.u = unit3(cross3(up, w));
+  c.v = unit3(cross3(w, c.u));
+  double half_height = focus * std::tan(fov / 2);
+  double half_width = aspect * half_height;
+  c.horizontal = c.u * static_cast<float>(2 * half_width);
+  c.vertical = c.v * static_cast<float>(2 * half_height);
+  c.llc = pos - w - c.u * static_cast<float>(half_width) - c.v * static_cast<float>(half_height);
+  c.lens_radius = (float)(aperture / 2);  // DiskRand(float radius) narrows lens_radius_ (camera.cu:64,74)
+  s.cam_w = w;
+  s.has_camera = true;
+}
+
+// camera.cu:40-47
+void camera_raw(Scene &s, V3 pos, V3 llc, V3 horiz, V3 vert) {
+  CameraDev &c = s.cam;
+  c.defocus = 0;
+  c.lens_radius = -1.f;
+  c.position = pos;
+  c.llc = llc;
+  c.horizontal = horiz;
+  c.vertical = vert;
+  c.u = splat(0.f);
+  c.v = splat(0.f);
+  s.cam_w = splat(0.f);
+  s.has_camera = true;
+}
+
+struct FacePts {
+  V3 p[3];
+  float uv[6];
+};
+
+// bvh.cuh:113-121: bounds; leaf if n <= kMin; else sort by positions_[0].x and
+// split at mid = (n-1)/2.  The sort key never changes down the tree, so the
+// reference's per-node re-sort of an already sorted sub-range is the identity for
+// a stable sort; one stable sort of the whole range reproduces it.  (thrust::sort
+// does not promise an order for equal keys; this build fixes it as stable.)
+static int build_bvh_nodes(std::vector<BvhNode> &nodes, const std::vector<FacePts> &fp, int first, int n,
+                           int leaf_max, int face_base) {
+  BvhNode nd;
+  for (int k = 0; k < 3; k++) nd.mn[k] = INFINITY, nd.mx[k] = -INFINITY;
+  for (int i = 0; i < n; i++)  // bvh.cuh:71-82
+    for (int j = 0; j < 3; j++) {
+      const V3 &p = fp[first + i].p[j];
+      const float c[3] = {p.x, p.y, p.z};
+      for (int k = 0; k < 3; k++) {
+        nd.mn[k] = fminf(c[k], nd.mn[k]);
+        nd.mx[k] = fmaxf(c[k], nd.mx[k]);
+      }
+    }
+  int me = (int)nodes.size();
+  nodes.push_back(nd);
+  if (n <= leaf_max) {
+    nodes[me].left = face_base + first;
+    nodes[me].right = -n;
+    return me;
+  }
+  int mid = (n - 1) / 2;
+  int l = build_bvh_nodes(nodes, fp, first, mid + 1, leaf_max, face_base);
+  int r = build_bvh_nodes(nodes, fp, first + mid + 1, n - mid - 1, leaf_max, face_base);
+  nodes[me].left = l;
+  nodes[me].right = r;
+  return me;
+}
+
+std::string Scene::flatten() {
+  runs.clear(), spheres.clear(), pgrams.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), faces.clear(),
+      face_uv.clear(), mat_recs.clear(), tex_recs.clear();
+  features = 0;
+  if (!has_camera) return "scene has no camera";
+  if (world.size() > 1024) return "world exceeds HitableList::kMaxHitables (1024)";
+  if (cam.defocus) features |= F_DEFOCUS;
+
+  // ---- materials: fold constant textures into the record; image textures by index
+  std::vector<int> tex_to_image(texs.size(), -1);
+  int n_images = 0;
+  for (size_t i = 0; i < texs.size(); i++)
+    if (texs[i].image) tex_to_image[i] = n_images++;
+  for (const HostMat &m : mats) {
+    MatRec r{};
+    r.kind = m.kind;
+    r.r = m.rgb.x, r.g = m.rgb.y, r.b = m.rgb.z;
+    r.param = m.param;
+    r.tex = -1;
+    if (m.tex >= 0) {
+      if (m.tex >= (int)texs.size()) return "material refers to an unknown texture";
+      const HostTex &t = texs[m.tex];
+      if (t.image) {
+        r.tex = tex_to_image[m.tex];
+        features |= F_TEX;
+      } else {
+        r.r = t.rgb.x, r.g = t.rgb.y, r.b = t.rgb.z;
+      }
+    }
+    mat_recs.push_back(r);
+  }
+
+  auto push_run = [&](int kind, int first) {
+    if (!runs.empty() && runs.back().kind == kind && runs.back().first + runs.back().count == first) {
+      runs.back().count++;
+    } else {
+      runs.push_back(Run{kind, first, 1, 0});
+    }
+  };
+  auto check_mat = [&](int m) { return m >= 0 && m < (int)mats.size(); };
+
+  bytes_per_ray = 32;  // material / hit-record share per query
+  for (const HostObj &ob : world) {
+    switch (ob.kind) {
+      case OBJ_SKY:
+        runs.push_back(Run{RUN_SKY, 0, 1, 0});
+        break;
+      case OBJ_SPHERE: {
+        if (!check_mat(ob.mat)) return "sphere without a valid material";
+        SphereRec r;
+        r.cx = ob.p[0].x, r.cy = ob.p[0].y, r.cz = ob.p[0].z;
+        r.mat = ob.mat;
+        r.radius = ob.radius;
+        r.r2 = ob.radius * ob.radius;
+        spheres.push_back(r);
+        push_run(RUN_SPHERE, (int)spheres.size() - 1);
+        features |= F_SPHERE;
+        bytes_per_ray += 28;
+        break;
+      }
+      case OBJ_TRI: {
+        if (!check_mat(ob.mat)) return "triangle without a valid material";
+        TriangleRec r{};
+        r.a = make_tri(ob.p[0], ob.p[1], ob.p[2]);
+        r.mat = ob.mat;
+        tris.push_back(r);
+        push_run(RUN_TRI, (int)tris.size() - 1);
+        features |= F_TRI;
+        bytes_per_ray += 40;
+        break;
+      }
+      case OBJ_PGRAM: {
+        if (!check_mat(ob.mat)) return "parallelogram without a valid material";
+        pgrams.push_back(make_pgram(ob.p[0], ob.p[1], ob.p[2], ob.mat));
+        push_run(RUN_PGRAM, (int)pgrams.size() - 1);
+        features |= F_PGRAM;
+        bytes_per_ray += 40;
+        break;
+      }
+      case OBJ_BOX: {
+        if (!check_mat(ob.mat)) return "parallelepiped without a valid material";
+        // parallelepiped.cu:25-32: AddCorner(p) then AddCorner(q), three faces each
+        for (int set = 0; set < 2; set++) {
+          const V3 *c = ob.p + set * 4;
+          for (int i = 1; i <= 3; i++) {
+            int x = i, y = (i + 1 == 4) ? 1 : x + 1;
+            pgrams.push_back(make_pgram(c[0], c[x], c[y], ob.mat));
+            push_run(RUN_PGRAM, (int)pgrams.size() - 1);
+            bytes_per_ray += 40;
+          }
+        }
+        features |= F_PGRAM;
+        break;
+      }
+      case OBJ_BVH: {
+        const HostBvh &hb = bvhs[ob.bvh];
+        if (hb.mat >= (int)mats.size()) return "bvh refers to an unknown material";
+        if (hb.mat < 0) return "bvh without a material (material_ptr_ == nullptr) is not renderable";
+        const bool has_uv = !hb.uvs.empty();
+        std::vector<FacePts> fp((size_t)hb.n);
+        for (int i = 0; i < hb.n; i++) {
+          for (int j = 0; j < 3; j++)
+            fp[i].p[j] = mk(hb.faces[(size_t)i * 9 + j * 3], hb.faces[(size_t)i * 9 + j * 3 + 1],
+                            hb.faces[(size_t)i * 9 + j * 3 + 2]);
+          for (int j = 0; j < 6; j++) fp[i].uv[j] = has_uv ? hb.uvs[(size_t)i * 6 + j] : 0.f;
+        }
+        int leaf_max = hb.leaf_max > 0 ? hb.leaf_max : 2048;
+        if (hb.n > leaf_max)
+          std::stable_sort(fp.begin(), fp.end(),
+                           [](const FacePts &a, const FacePts &b) { return a.p[0].x < b.p[0].x; });
+        int face_base = (int)faces.size();
+        if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
+        for (int i = 0; i < hb.n; i++) {
+          TriRec t = make_tri(fp[i].p[0], fp[i].p[1], fp[i].p[2]);
+          FaceRec f;
+          for (int c = 0; c < 3; c++) f.p0[c] = t.p0[c], f.e1[c] = t.e1[c], f.e2[c] = t.e2[c], f.n[c] = t.n[c];
+          faces.push_back(f);
+          if (has_uv)
+            for (int j = 0; j < 6; j++) face_uv.push_back(fp[i].uv[j]);
+        }
+        BvhRec br{};
+        // an empty mesh is a leaf that can never report a hit: it contributes nothing
+        br.root = hb.n > 0 ? build_bvh_nodes(nodes, fp, 0, hb.n, leaf_max, face_base) : -1;
+        br.mat = hb.mat;
+        br.has_uv = has_uv ? 1 : 0;
+        if (br.root >= 0) {
+          bvh_recs.push_back(br);
+          push_run(RUN_BVH, (int)bvh_recs.size() - 1);
+          features |= F_BVH;
+        }
+        break;
+      }
+    }
+  }
+  if (!face_uv.empty()) face_uv.resize(faces.size() * 6, 0.f);
+  return "";
+}
+
+}  // namespace rtmi

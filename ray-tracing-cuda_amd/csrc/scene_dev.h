@@ -1,0 +1,135 @@
+// Device-resident scene layout consumed by the trace kernel.
+//
+// Access pattern decides the layout (DESIGN.md "Data layout in HBM"):
+//  * world runs, spheres, parallelograms, triangles are read at a wave-uniform
+//    index by every lane at once -> packed, 32/64/128-byte aligned records that
+//    one s_load_dwordx8/x16 brings into SGPRs (scalar cache), ray-independent
+//    terms (edges, unit normal, r^2) precomputed on the host with the same
+//    binary32 operations the reference performs per ray;
+//  * BVH nodes / faces are gathered per lane -> 16-byte aligned records read
+//    with dwordx4 loads;
+//  * per-pixel data (RNG state, radiance) is struct-of-arrays / tile-major so a
+//    wave's loads and stores are contiguous;
+//  * the material table is small and indexed per lane -> staged in LDS.
+#pragma once
+#include <stdint.h>
+
+#include "vec.h"
+
+namespace rtmi {
+
+enum RunKind : int32_t { RUN_SKY = 0, RUN_SPHERE = 1, RUN_PGRAM = 2, RUN_TRI = 3, RUN_BVH = 4 };
+
+// A maximal stretch of consecutive world-list entries of one kind, in list
+// order (order carries the tie rule of HitableList::Hit, hitable_list.cu:18).
+struct Run {
+  int32_t kind, first, count, pad;
+};
+
+struct SphereRec {  // 32 B
+  float cx, cy, cz;
+  int32_t mat;
+  double radius;
+  double r2;  // radius * radius (pow(radius, 2), sphere.cu:16)
+};
+
+struct TriRec {  // 48 B: Moller-Trumbore operands that do not depend on the ray
+  float p0[3];
+  float e1[3];  // p1 - p0
+  float e2[3];  // p2 - p0
+  float n[3];   // normalize(cross(e1, e2))   (utils.cu:79)
+};
+
+struct PgramRec {  // 128 B: triangles (p0,p1,p2) and (p1,p2,p3), parallelogram.cu:25,33
+  TriRec a, b;
+  int32_t mat;
+  int32_t pad[7];
+};
+
+struct TriangleRec {  // 64 B
+  TriRec a;
+  int32_t mat;
+  int32_t pad[3];
+};
+
+enum MatKind : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_SKY = 4 };
+
+struct MatRec {  // 32 B
+  int32_t kind;
+  float r, g, b;   // constant albedo / attenuation / emission
+  float param;     // Metal: fuzz (already min(fuzz,1)); Dielectric: (float)refractive_index
+  int32_t tex;     // >= 0: image texture supplies the colour instead of r,g,b
+  int32_t pad[2];
+};
+
+struct TexRec {  // 32 B
+  const uint8_t *rgba;  // pitched RGBA8 in device memory
+  int32_t height, width;
+  int64_t pitch;
+  int64_t pad;
+};
+
+struct BvhNode {  // 32 B
+  float mn[3];
+  float mx[3];
+  int32_t left;   // inner: index of left child; leaf: first face
+  int32_t right;  // inner: index of right child; leaf: -(face count)  (negative marks a leaf)
+};
+
+struct BvhRec {  // one per BVH hitable
+  int32_t root;      // node index
+  int32_t mat;       // -1: keep "material_ptr_ == nullptr"
+  int32_t has_uv;
+  int32_t pad;
+};
+
+struct FaceRec {  // 48 B, 16-byte aligned
+  float p0[3];
+  float e1[3];
+  float e2[3];
+  float n[3];
+};
+
+struct CameraDev {
+  V3 position, llc, horizontal, vertical, u, v;
+  float lens_radius;
+  int32_t defocus;
+};
+
+constexpr int kLdsMats = 512;  // material records staged in LDS (16 KiB)
+
+struct SceneDev {
+  const Run *runs;
+  const SphereRec *spheres;
+  const PgramRec *pgrams;
+  const TriangleRec *tris;
+  const BvhRec *bvhs;
+  const BvhNode *nodes;
+  const FaceRec *faces;
+  const float *face_uv;  // 6 floats per face or nullptr
+  const MatRec *mats;
+  const TexRec *texs;
+  int32_t n_runs, n_mats;
+  CameraDev cam;
+};
+
+// Feature bits selecting a kernel specialisation.
+enum : uint32_t {
+  F_SPHERE = 1u,   // double-precision t
+  F_PGRAM = 2u,
+  F_TRI = 4u,
+  F_BVH = 8u,
+  F_TEX = 16u,     // some material reads an image texture (u,v needed)
+  F_DEFOCUS = 32u,
+  F_ALL = 63u
+};
+
+struct FrameDev {
+  int32_t height, width, spp, max_depth, post;
+  int32_t rank, world;
+  int32_t tiles_x, tiles_y, n_tiles;   // global tile grid
+  int32_t local_tiles;                 // tiles owned by this rank
+  int64_t items;                       // local_tiles * 64
+};
+
+}  // namespace rtmi
