@@ -90,6 +90,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RtmiError("%s is missing: build it with __graft_entry__.build() "
                             "(make -C ray-tracing-cuda_amd/csrc); there is no CPU fallback" % LIB_PATH)
+        # PyTorch bundles its own HIP runtime (torch/lib/libamdhip64.so).  Import torch first so
+        # librtmi.so binds to that already-loaded runtime; loading /opt/rocm's copy first would
+        # put two HIP runtimes in one process and torch would then see no device.
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)
