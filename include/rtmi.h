@@ -132,6 +132,8 @@ int64_t rtmi_scene_bytes_per_ray(const rtmi_scene *s);
 int64_t rtmi_frame_work_items(const rtmi_frame *f);
 /* Global pixel index (i*width+j) of work item q of this shard, or -1 for padding. */
 int64_t rtmi_frame_pixel_of(const rtmi_frame *f, int64_t q);
+/* Bulk form: out[q] for every work item q of this shard (out has rtmi_frame_work_items entries). */
+int rtmi_frame_pixel_map(const rtmi_frame *f, int64_t *out);
 /* Bytes the caller must allocate for d_states / d_tiles of this shard. */
 size_t rtmi_states_bytes(const rtmi_frame *f);   /* 6 planes of uint32[work_items] (struct-of-arrays) */
 size_t rtmi_tiles_bytes(const rtmi_frame *f);    /* float[work_items][3] */

@@ -348,6 +348,12 @@ int64_t rtmi_frame_pixel_of(const rtmi_frame *f, int64_t q) {
   if (!make_frame(f, &d) || q < 0 || q >= d.items) return -1;
   return frame_pixel_of(d, d.rank, q);
 }
+int rtmi_frame_pixel_map(const rtmi_frame *f, int64_t *out) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !out) return fail(RTMI_ERR_INVALID, "bad frame");
+  for (int64_t q = 0; q < d.items; q++) out[q] = frame_pixel_of(d, d.rank, q);
+  return RTMI_OK;
+}
 size_t rtmi_states_bytes(const rtmi_frame *f) {
   FrameDev d;
   if (!make_frame(f, &d)) return 0;

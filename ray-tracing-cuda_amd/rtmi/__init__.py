@@ -66,6 +66,7 @@ SYMBOLS = [
     ("rtmi_scene_bytes_per_ray", C.c_int64, [C.c_void_p]),
     ("rtmi_frame_work_items", C.c_int64, [_frp]),
     ("rtmi_frame_pixel_of", C.c_int64, [_frp, C.c_int64]),
+    ("rtmi_frame_pixel_map", C.c_int, [_frp, C.POINTER(C.c_int64)]),
     ("rtmi_states_bytes", C.c_size_t, [_frp]),
     ("rtmi_tiles_bytes", C.c_size_t, [_frp]),
     ("rtmi_rng_init", C.c_int, [C.c_uint64, _frp, C.c_void_p, C.c_void_p]),
@@ -124,9 +125,10 @@ def work_items(frame):
 
 def pixel_map(frame):
     """int64 array: global pixel index of each work item of this shard (-1 = padding)."""
-    n = work_items(frame)
-    L = lib()
-    return np.array([L.rtmi_frame_pixel_of(C.byref(frame), q) for q in range(n)], dtype=np.int64)
+    out = np.empty(work_items(frame), dtype=np.int64)
+    _check(lib().rtmi_frame_pixel_map(C.byref(frame), out.ctypes.data_as(C.POINTER(C.c_int64))),
+           "rtmi_frame_pixel_map")
+    return out
 
 
 def get_workload(rank, world_size, spp):

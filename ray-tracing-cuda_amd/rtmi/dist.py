@@ -36,10 +36,8 @@ def gather_to_root(t, dst=0):
 
 def shard_pixel_map(height, width, rank, world_size):
     """Global pixel index of every work item of a shard (-1 for padding); host arithmetic only."""
-    f = Frame(height, width, 1, 1, 0, rank, world_size)
-    n = work_items(f)
-    L = lib()
-    return np.array([L.rtmi_frame_pixel_of(C.byref(f), q) for q in range(n)], dtype=np.int64)
+    from . import pixel_map
+    return pixel_map(Frame(height, width, 1, 1, 0, rank, world_size))
 
 
 def untile_host(all_tiles, height, width, world_size):

@@ -5,8 +5,8 @@ A *builder* is any object exposing the reference's constructors as methods
 (``lambertian(rgb)``, ``sphere(center, radius, mat)``, ``parallelogram(p, mat)``,
 ``parallelepiped_lengths(lengths, mat, transform)``, ``sky()``, ``bvh(faces, mat)``,
 ``camera_pinhole(...)``, ``random_float(mn, mx)`` ...).  The product's builder
-(``rtmi.SceneBuilder``) forwards to the C-ABI of librtmi.so; the test oracle has its
-own builder over liboracle.so.  Scene programs are *inputs*: they contain no
+(``rtmi.SceneBuilder``) forwards to the C-ABI of librtmi.so; the test suite supplies a
+second builder over its CPU checker.  Scene programs are *inputs*: they contain no
 rendering arithmetic, only the constants of the reference's ``InitWorld`` kernels.
 
 All vector constants are rounded to binary32 exactly as ``glm::vec3(double literals)``

@@ -1,0 +1,80 @@
+"""BASELINE.json full-size configurations on the GPU, checked through properties that do not
+need a full CPU render: (a) a random sample of pixels of the FULL config against the oracle
+(the oracle renders just those pixels: same seed, same subsequence, all 1024 spp), (b)
+shard invariance, (c) run-to-run determinism, (d) ray accounting."""
+import numpy as np
+import pytest
+
+import common
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_pixels(name, h, w, spp, depth, ids, **kw):
+    import oraclelib
+    b = common.build_scene(oraclelib.OracleBuilder(common.scene_seed(name)), name, w / h, **kw)
+    rgb, rays, _, _ = b.render(h, w, spp, depth, pixel_ids=ids)
+    return rgb.reshape(-1, 3)[ids], rays.reshape(-1)[ids]
+
+
+def test_c2_cornell_1024sq_1024spp_depth50_sampled_pixels():
+    """configs[1] at full size: 96 random pixels (plus the corners) bit-exact vs the oracle."""
+    h = w = 1024
+    spp, depth = 1024, 50
+    g_rgb, g_rays, _, g_total, _ = common.gpu_render("cornell_box", h, w, spp, depth)
+    rng = np.random.default_rng(2026)
+    ids = np.unique(np.concatenate([rng.integers(0, h * w, 96), [0, w - 1, (h - 1) * w, h * w - 1]])).astype(np.int32)
+    o_rgb, o_rays = _oracle_pixels("cornell_box", h, w, spp, depth, ids)
+    assert np.array_equal(g_rays.reshape(-1)[ids], o_rays)
+    assert np.array_equal(g_rgb.reshape(-1, 3)[ids], o_rgb)
+    assert g_total == int(g_rays.astype(np.uint64).sum())
+    assert g_rays.min() >= spp and g_rays.max() <= spp * (depth + 1)
+    assert np.isfinite(g_rgb).all() and g_rgb.min() >= 0 and g_rgb.max() <= 1
+
+
+def test_c2_shape_shard_invariance_and_determinism():
+    """1024x1024 frame at reduced spp: 1 shard == 8 shards == a second run, bit for bit."""
+    h = w = 1024
+    a = common.gpu_render("cornell_box", h, w, 4, 50)
+    b = common.gpu_render("cornell_box", h, w, 4, 50, world_size=8)
+    c = common.gpu_render("cornell_box", h, w, 4, 50)
+    for other in (b, c):
+        assert np.array_equal(a[0], other[0]) and np.array_equal(a[1], other[1]) and a[3] == other[3]
+
+
+def test_c3_bunny_mesh_1024sq_sampled_pixels():
+    """configs[2] shape (procedural stand-in mesh, 70,272 faces, reference leaf size 2048) at
+    1024x1024 with reduced spp; sampled pixels bit-exact vs the oracle."""
+    from rtmi import scenes
+    h = w = 1024
+    spp, depth = 2, 10
+    faces = scenes.procedural_bunny_mesh()
+    g_rgb, g_rays, _, g_total, _ = common.gpu_render("bunny", h, w, spp, depth, faces=faces)
+    rng = np.random.default_rng(7)
+    # bias the sample towards the mesh (centre of the frame)
+    ii = rng.integers(300, 724, 200)
+    jj = rng.integers(300, 724, 200)
+    ids = np.unique(np.concatenate([ii * w + jj, rng.integers(0, h * w, 56)])).astype(np.int32)
+    o_rgb, o_rays = _oracle_pixels("bunny", h, w, spp, depth, ids, faces=faces)
+    assert np.array_equal(g_rays.reshape(-1)[ids], o_rays)
+    assert np.array_equal(g_rgb.reshape(-1, 3)[ids], o_rgb)
+    assert (g_rays.reshape(-1)[ids] > spp).any()  # some sampled pixels do bounce off the mesh
+
+
+def test_c4_c5_shapes_sampled_pixels():
+    """configs[3] (cornell 2048^2) and configs[4] (birthday 4096^2) frame shapes at reduced spp,
+    rendered as 8 shards; sampled pixels vs the oracle (birthday within the texel tolerance)."""
+    from rtmi import scenes
+    rng = np.random.default_rng(11)
+    h = w = 2048
+    g_rgb, g_rays, _, _, _ = common.gpu_render("cornell_box", h, w, 2, 50, world_size=8)
+    ids = np.unique(rng.integers(0, h * w, 128)).astype(np.int32)
+    o_rgb, o_rays = _oracle_pixels("cornell_box", h, w, 2, 50, ids)
+    assert np.array_equal(g_rays.reshape(-1)[ids], o_rays) and np.array_equal(g_rgb.reshape(-1, 3)[ids], o_rgb)
+    h = w = 4096
+    tex = scenes.procedural_earthmap(256, 512)
+    g_rgb, g_rays, _, _, _ = common.gpu_render("birthday", h, w, 1, 10, world_size=8, earthmap=tex)
+    ids = np.unique(rng.integers(0, h * w, 128)).astype(np.int32)
+    o_rgb, o_rays = _oracle_pixels("birthday", h, w, 1, 10, ids, earthmap=tex)
+    assert np.array_equal(g_rays.reshape(-1)[ids], o_rays)
+    assert common.rel_l2(g_rgb.reshape(-1, 3)[ids], o_rgb) <= 1e-3

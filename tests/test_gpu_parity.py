@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C ABI of librtmi.so) with the CPU oracle.
+
+Bar: the north-star tolerance is 1e-3 relative L2 per frame.  Because the kernel performs
+the reference's operations one IEEE rounding at a time (-ffp-contract=off), these tests
+hold the stronger bar — images, per-pixel ray counts and final RNG states are BIT-EXACT —
+wherever no transcendental feeds a decision; the only exception is the image-textured
+sphere (acosf/atan2f from two libms pick a texel), held to the stated 1e-3 tolerance.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import common
+from test_golden import FILES, parse_case
+
+pytestmark = pytest.mark.gpu
+
+REL_L2_TOL = 1e-3  # north_star: "image within 1e-3 relative L2 of reference"
+
+
+def assert_parity(name, g, o, exact=True):
+    g_rgb, g_rays, g_states, g_total = g
+    o_rgb, o_rays, o_states, o_total = o
+    rel = common.rel_l2(g_rgb, o_rgb)
+    assert rel <= REL_L2_TOL, "%s: rel L2 %.3e" % (name, rel)
+    assert g_total == o_total, "%s: total rays %d vs %d" % (name, g_total, o_total)
+    assert np.array_equal(g_rays, o_rays), "%s: %d pixels with different ray counts" % (name, (g_rays != o_rays).sum())
+    if exact:
+        assert np.array_equal(g_rgb, o_rgb), "%s: max abs diff %g" % (name, np.abs(g_rgb - o_rgb).max())
+
+
+def gpu_states_rowmajor(states, h, w, world=1):
+    """(H*W, 6) uint32 from the per-rank SoA planes [6][items]."""
+    import rtmi
+    out = np.zeros((h * w, 6), dtype=np.uint32)
+    for r, st in enumerate(states):
+        pm = rtmi.pixel_map(rtmi.make_frame(h, w, 1, rank=r, world_size=world))
+        planes = st.cpu().numpy().view(np.uint32)  # (6, items)
+        ok = pm >= 0
+        out[pm[ok]] = planes[:, ok].T
+    return out
+
+
+@pytest.mark.parametrize("name,h,w,spp,depth,kw", [
+    ("sky_only", 16, 24, 2, 10, {}),
+    ("cornell_box", 48, 48, 8, 10, {}),
+    ("cornell_box", 40, 40, 4, 50, {}),
+    ("spheres", 40, 56, 4, 8, {}),
+    ("mixed", 40, 40, 8, 10, {}),
+    ("furnace", 24, 24, 8, 10, {}),
+    ("bunny", 40, 40, 4, 10, {"k_min": 64}),
+    ("bunny", 32, 32, 2, 10, {"k_min": 2048}),
+])
+def test_scene_bit_exact(name, h, w, spp, depth, kw):
+    g_rgb, g_rays, g_states, g_total, _ = common.gpu_render(name, h, w, spp, depth, **kw)
+    o_rgb, o_rays, o_states, o_total, _ = common.oracle_render(name, h, w, spp, depth, **kw)
+    assert_parity(name, (g_rgb, g_rays, g_states, g_total), (o_rgb, o_rays, o_states, o_total))
+    assert np.array_equal(gpu_states_rowmajor(g_states, h, w), o_states), "final RNG states differ"
+
+
+def test_image_textured_sphere_within_tolerance():
+    g_rgb, g_rays, _, g_total, _ = common.gpu_render("birthday", 48, 48, 8, 10)
+    o_rgb, o_rays, _, o_total, _ = common.oracle_render("birthday", 48, 48, 8, 10)
+    assert_parity("birthday", (g_rgb, g_rays, None, g_total), (o_rgb, o_rays, None, o_total), exact=False)
+    assert (g_rgb == o_rgb).all(axis=2).mean() > 0.99
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_against_golden_vectors(path):
+    name, h, w, spp, depth, post, kw = parse_case(path)
+    gold = np.load(path)
+    g_rgb, g_rays, g_states, g_total, _ = common.gpu_render(name, h, w, spp, depth, post=post, **kw)
+    assert g_total == int(gold["total"])
+    assert np.array_equal(g_rays, gold["rays"])
+    assert np.array_equal(gpu_states_rowmajor(g_states, h, w), gold["states"])
+    if name == "birthday":
+        assert common.rel_l2(g_rgb, gold["rgb"]) <= REL_L2_TOL
+    else:
+        assert np.array_equal(g_rgb, gold["rgb"])
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 9), (37, 53), (8, 120)])
+def test_ragged_frames(h, w):
+    g = common.gpu_render("cornell_box", h, w, 3, 10)
+    o = common.oracle_render("cornell_box", h, w, 3, 10)
+    assert_parity("cornell %dx%d" % (h, w), g[:4], o[:4])
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 8, 64])
+def test_depth_limits(depth):
+    g = common.gpu_render("cornell_box", 24, 24, 4, depth)
+    o = common.oracle_render("cornell_box", 24, 24, 4, depth)
+    assert_parity("depth %d" % depth, g[:4], o[:4])
+    if depth == 0:
+        assert g[0].max() == 0.0 and (g[1] == 4).all()
+
+
+def test_depth_above_limit_is_rejected():
+    import rtmi
+    b = common.build_scene(rtmi.SceneBuilder(1024), "cornell_box").commit()
+    R = rtmi.Renderer(b, 8, 8, 1, 65).init_rng()
+    with pytest.raises(rtmi.RtmiError) as e:
+        R.render()
+    assert "(-5)" in str(e.value)
+
+
+def test_raw_sums_and_root_side_post_process():
+    """DistributedMain renders raw sums (post=false) and the root applies sqrt(clamp(sum/spp))
+    (utils.cu:126-129): rtmi_post_process on the raw frame == the kernel's own post-process."""
+    import ctypes as C
+    import torch
+    import rtmi
+    h, w, spp = 24, 24, 5
+    raw = common.gpu_render("mixed", h, w, spp, 10, post=False)
+    o_raw = common.oracle_render("mixed", h, w, spp, 10, post=False)
+    assert_parity("raw", raw[:4], o_raw[:4])
+    post = common.gpu_render("mixed", h, w, spp, 10, post=True)
+    t = torch.from_numpy(raw[0].copy()).cuda()
+    assert rtmi.lib().rtmi_post_process(C.c_void_p(t.data_ptr()), h * w, spp, None) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy(), post[0])
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_shards_reproduce_the_single_gpu_frame(world):
+    """Quirk-free sharding: every pixel keeps subsequence == global index, so the frame
+    assembled from `world` shards is bit-identical to the 1-GPU frame (and to the oracle)."""
+    h, w, spp = 40, 56, 4
+    one = common.gpu_render("spheres", h, w, spp, 8)
+    many = common.gpu_render("spheres", h, w, spp, 8, world_size=world)
+    assert np.array_equal(one[0], many[0]) and np.array_equal(one[1], many[1]) and one[3] == many[3]
+    assert np.array_equal(gpu_states_rowmajor(many[2], h, w, world), gpu_states_rowmajor(one[2], h, w))
+
+
+def test_defocus_camera():
+    import oraclelib
+    import rtmi
+    from rtmi.scenes import v3, PI_D
+
+    def fill(b):
+        b.camera_defocus(v3(0, 1.5, 6), v3(0, 0.8, 0), v3(0, 1, 0), PI_D / 4, 1.0, 0.4, 6.0)
+        g = b.lambertian(v3(0.5, 0.5, 0.5))
+        b.sphere(v3(0, -100, 0), 100.0, g)
+        b.sky()
+        b.sphere(v3(0, 0.7, 0), 0.7, b.metal(v3(0.8, 0.6, 0.2), 0.2))
+        return b
+
+    import torch
+    h = w = 32
+    spp = 6
+    o = fill(oraclelib.OracleBuilder(77))
+    o_rgb, o_rays, o_st, o_tot = o.render(h, w, spp, 10)
+    p = fill(rtmi.SceneBuilder(77)).commit()
+    R = rtmi.Renderer(p, h, w, spp, 10).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert R.total_rays() == o_tot
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb)
+
+
+def test_bvh_with_texture_coordinates_and_inner_nodes():
+    """Face<true> mesh (bvh.cuh:21-49) with an image-textured Lambertian, leaves of 32 faces."""
+    import oraclelib
+    import rtmi
+    import torch
+    from rtmi import scenes
+    from rtmi.scenes import v3, PI_D
+    faces = scenes.procedural_bunny_mesh(20, 16)
+    rng = np.random.default_rng(5)
+    uvs = rng.uniform(0, 1, size=(faces.shape[0], 6)).astype(np.float32)
+    tex = scenes.procedural_earthmap(32, 64)
+
+    def fill(b):
+        b.camera_pinhole(v3(-0.025, 0.1, -0.5), v3(-0.025, 0.1, 0), v3(0, 1, 0), PI_D * 2 / 9, 1.0)
+        b.sky()
+        m = b.lambertian_tex(b.image_texture(tex))
+        b.bvh(faces, m, uvs=uvs, k_min=32)
+        return b
+
+    h = w = 40
+    o = fill(oraclelib.OracleBuilder(3))
+    o_rgb, o_rays, _, o_tot = o.render(h, w, 4, 10)
+    p = fill(rtmi.SceneBuilder(3)).commit()
+    assert p.stats()["bvh_nodes"] > 3
+    R = rtmi.Renderer(p, h, w, 4, 10).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert R.total_rays() == o_tot
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb)
+
+
+def test_rng_init_on_device_matches_oracle():
+    import ctypes as C
+    import torch
+    import oraclelib
+    import rtmi
+    for seed, h, w, world in [(1024, 37, 53, 1), (10086, 64, 64, 3), (0xdeadbeefcafe, 16, 16, 2)]:
+        want = oraclelib.rng_init(seed, h * w)
+        states = []
+        for r in range(world):
+            f = rtmi.make_frame(h, w, 1, rank=r, world_size=world)
+            n = rtmi.work_items(f)
+            st = torch.zeros((6, n), dtype=torch.int32, device="cuda")
+            assert rtmi.lib().rtmi_rng_init(C.c_uint64(seed), C.byref(f), C.c_void_p(st.data_ptr()), None) == 0
+            states.append(st)
+        torch.cuda.synchronize()
+        assert np.array_equal(gpu_states_rowmajor(states, h, w, world), want)
+
+
+def test_c1_spheres_full_config():
+    """BASELINE configs[0]: scenes/spheres 256x256, 16 spp, depth 8 — full size vs the oracle."""
+    g = common.gpu_render("spheres", 256, 256, 16, 8)
+    o = common.oracle_render("spheres", 256, 256, 16, 8)
+    assert_parity("C1", g[:4], o[:4])

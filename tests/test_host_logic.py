@@ -1,0 +1,151 @@
+"""Host-side logic of the product (no GPU): C-ABI surface, frame/tile arithmetic, scene
+recorder bookkeeping, error behaviour, and the float-threshold facts the kernel relies on."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import common
+import oraclelib
+import rtmi
+from rtmi import scenes
+from rtmi.scenes import v3
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rtmi_[a-z0-9_]+)\s*\(", hdr)) - {"rtmi_transform_fn"}
+    assert len(declared) >= 40
+    L = rtmi.lib()
+    bound = {n for n, _, _ in rtmi.SYMBOLS}
+    for name in sorted(declared):
+        assert hasattr(L, name), "librtmi.so does not export %s" % name
+        assert name in bound, "%s is not bound in rtmi.SYMBOLS" % name
+    assert L.rtmi_version() == 1
+
+
+def test_float_thresholds_used_by_the_kernel():
+    """kernels.hip replaces two double compares of the reference by float compares:
+    '1e-3 <= t' (ray_tracing.cu:22 -> utils.cu:74) and 'fabs(det) < 1e-7' (utils.cu:60).
+    Valid because the binary32 nearest to each constant lies ABOVE it and t/det are binary32."""
+    f = np.float32
+    assert float(f(1e-3)) > 1e-3 and float(np.nextafter(f(1e-3), f(0))) < 1e-3
+    assert float(f(1e-7)) > 1e-7 and float(np.nextafter(f(1e-7), f(0))) < 1e-7
+    assert float(f(1e9)) == 1e9  # Sky's t is exact in binary32 (sky.cu:20)
+
+
+@pytest.mark.parametrize("h,w", [(8, 8), (20, 30), (37, 53), (64, 64), (1, 1), (9, 200)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_tile_shards_partition_the_frame(h, w, world):
+    seen = np.zeros(h * w, dtype=np.int32)
+    sizes = set()
+    for r in range(world):
+        f = rtmi.make_frame(h, w, 1, rank=r, world_size=world)
+        pm = rtmi.pixel_map(f)
+        sizes.add(pm.size)
+        assert pm.size % 64 == 0
+        ok = pm[pm >= 0]
+        seen[ok] += 1
+        # a tile's 64 work items are one 8x8 block, row-major
+        for t in range(pm.size // 64):
+            blk = pm[t * 64:(t + 1) * 64]
+            if (blk >= 0).all():
+                i, j = blk // w, blk % w
+                assert (i - i[0] == np.repeat(np.arange(8), 8)).all() and (j - j[0] == np.tile(np.arange(8), 8)).all()
+    assert (seen == 1).all()
+    assert len(sizes) == 1  # every rank has the same number of work items (gather stride)
+
+
+def test_frame_validation():
+    L = rtmi.lib()
+    bad = rtmi.make_frame(0, 8, 1)
+    assert L.rtmi_frame_work_items(C.byref(bad)) < 0
+    bad = rtmi.make_frame(8, 8, 1, rank=2, world_size=2)
+    assert L.rtmi_frame_work_items(C.byref(bad)) < 0
+    ok = rtmi.make_frame(16, 16, 1)
+    assert L.rtmi_states_bytes(C.byref(ok)) == 4 * 64 * 6 * 4
+    assert L.rtmi_tiles_bytes(C.byref(ok)) == 4 * 64 * 3 * 4
+    assert L.rtmi_frame_pixel_of(C.byref(ok), 10 ** 9) == -1
+
+
+def test_get_workload_matches_oracle():
+    for spp in [1, 20, 100, 1024]:
+        for world in [1, 3, 8]:
+            for r in range(world):
+                assert rtmi.get_workload(r, world, spp) == oraclelib.lib().orc_get_workload(r, world, spp)
+
+
+def test_scene_stats_and_bytes_per_ray():
+    b = common.build_scene(rtmi.SceneBuilder(1024), "cornell_box")
+    st = b.stats()
+    assert st["world"] == 9 and st["parallelograms"] == 18 and st["materials"] == 4
+    assert b.bytes_per_ray() == 18 * 40 + 32  # 752 B/ray
+    b = common.build_scene(rtmi.SceneBuilder(10086), "spheres")
+    assert b.bytes_per_ray() == 488 * 28 + 32  # 13.7 KB/ray
+
+
+def test_camera_matches_oracle_bitwise():
+    for name in ["cornell_box", "spheres", "bunny", "mixed"]:
+        p = common.build_scene(rtmi.SceneBuilder(5), name, 16 / 9)
+        o = common.build_scene(oraclelib.OracleBuilder(5), name, 16 / 9)
+        assert np.array_equal(p.camera_get(), o.camera_get())
+    p, o = rtmi.SceneBuilder(1), oraclelib.OracleBuilder(1)
+    for b in (p, o):
+        b.camera_defocus(v3(1, 2, 3), v3(0, 0.5, 0), v3(0, 1, 0), 0.7, 1.5, 0.3, 4.0)
+    assert np.array_equal(p.camera_get(), o.camera_get())
+
+
+def test_scene_time_rng_draws_match_oracle():
+    p = common.build_scene(rtmi.SceneBuilder(10086), "spheres")
+    o = common.build_scene(oraclelib.OracleBuilder(10086), "spheres")
+    assert np.array_equal(p.state0, o.state0) and not np.array_equal(p.state0, p.state0_fresh)
+
+
+def test_error_behaviour():
+    L = rtmi.lib()
+    b = rtmi.SceneBuilder(1)
+    white = b.lambertian(v3(1, 1, 1))
+    with pytest.raises(rtmi.RtmiError):
+        b.sphere(v3(0, 0, 0), 1.0, 99)  # unknown material handle
+    with pytest.raises(rtmi.RtmiError):
+        b.lambertian_tex(7)  # unknown texture handle
+    with pytest.raises(rtmi.RtmiError):
+        b.stats()  # no camera yet
+    assert b"camera" in L.rtmi_last_error()
+    b.camera_pinhole(v3(0, 0, 1), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+    for _ in range(1024):
+        b.sphere(v3(0, 0, 0), 1.0, white)
+    with pytest.raises(rtmi.RtmiError) as e:  # HitableList::kMaxHitables (hitable_list.cuh:10)
+        b.sphere(v3(0, 0, 0), 1.0, white)
+    assert "(-4)" in str(e.value)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point must fail loudly, never render on the CPU."""
+    L = rtmi.lib()
+    if L.rtmi_device_count() > 0:
+        pytest.skip("a GPU is present")
+    b = common.build_scene(rtmi.SceneBuilder(1024), "cornell_box")
+    with pytest.raises(rtmi.RtmiError) as e:
+        b.commit()
+    assert "(-2)" in str(e.value) and "no CPU fallback" in str(e.value)
+    f = rtmi.make_frame(8, 8, 1)
+    buf = (C.c_uint32 * (64 * 6))()
+    assert L.rtmi_rng_init(C.c_uint64(1), C.byref(f), buf, None) == -2
+    with pytest.raises(rtmi.RtmiError):
+        rtmi.Renderer(b, 8, 8, 1)
+
+
+def test_product_does_not_import_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "ray-tracing-cuda_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cuh", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oraclelib" not in txt and "liboracle" not in txt and "oracle/" not in txt, fn
