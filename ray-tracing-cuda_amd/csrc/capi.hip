@@ -289,7 +289,6 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   int rc;
   if ((rc = upload(s, s->runs, &d.runs))) return rc;
   if ((rc = upload(s, s->spheres, &d.spheres))) return rc;
-  if ((rc = upload(s, s->pgrams, &d.pgrams))) return rc;
   if ((rc = upload(s, s->tris, &d.tris))) return rc;
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
@@ -318,9 +317,9 @@ int rtmi_scene_stats(const rtmi_scene *sp, int64_t out[8]) {
   std::string err = tmp.flatten();
   if (!err.empty()) return fail(RTMI_ERR_INVALID, err);
   out[0] = (int64_t)tmp.world.size();
-  out[1] = (int64_t)tmp.spheres.size();
-  out[2] = (int64_t)tmp.pgrams.size();
-  out[3] = (int64_t)tmp.tris.size();
+  out[1] = (int64_t)tmp.n_spheres;
+  out[2] = (int64_t)tmp.n_pgrams;
+  out[3] = (int64_t)tmp.n_triangles;
   out[4] = (int64_t)tmp.faces.size();
   out[5] = (int64_t)tmp.nodes.size();
   out[6] = (int64_t)tmp.mat_recs.size();
@@ -429,7 +428,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   HIP_TRY(hipGetDeviceProperties(&prop, dev));
   const int threads = g_threads > 0 ? g_threads : 256;
   const uint32_t variant = pick_variant(s->features);
-  int per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : render_occupancy(variant, threads);
+  int per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : render_occupancy(variant, s->dev, d, threads);
   if (per_cu <= 0) per_cu = 1;
   int64_t want = (d.items + threads - 1) / threads;
   int64_t cap = (int64_t)prop.multiProcessorCount * per_cu;

@@ -16,7 +16,7 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
 
 // Kernel specialisation covering a feature set, its occupancy, and its launch.
 uint32_t pick_variant(uint32_t features);
-int render_occupancy(uint32_t variant, int threads);
+int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads);
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
                          hipStream_t stream);

@@ -15,7 +15,10 @@
 //     geometry traffic at all for list scenes;
 //   * acceptance bookkeeping in the loop is 3 VGPRs (ok, t_to, winner id); the
 //     winner's normal / material are resolved once per ray after the loop;
-//   * the material table is staged in LDS once per workgroup;
+//   * the material table is staged in LDS once per workgroup, and so is the per-lane
+//     stack of scattered-material ids that the back-to-front radiance fold of
+//     ray_tracing.cu:50-52 needs (one byte per bounce instead of a 12-byte
+//     attenuation in scratch memory);
 //   * arithmetic follows the reference operation by operation (binary32 with
 //     the binary64 islands of sphere.cu / ray_tracing.cu:68-73); the file is
 //     compiled with -ffp-contract=off and IEEE divide/sqrt.
@@ -111,7 +114,6 @@ struct TSel<true> {
 // Winner id: kind in the top 3 bits, index below; bit 28 marks the second
 // triangle of a parallelogram.
 constexpr uint32_t ID_NONE = 0xffffffffu;
-constexpr uint32_t ID_SECOND = 1u << 28;
 constexpr uint32_t ID_INDEX_MASK = (1u << 28) - 1;
 __device__ __forceinline__ uint32_t make_id(int kind, int index) { return ((uint32_t)kind << 29) | (uint32_t)index; }
 
@@ -139,10 +141,43 @@ __device__ __forceinline__ bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to
   if (!(T_FROM_F <= t && (T)t <= t_to)) return false;
   return true;
 }
+// The same test as straight-line code.  In the world-list loop all 64 lanes test the SAME
+// triangle with unrelated rays, so some lane nearly always survives each early-out and
+// the exec-mask branches only cost scalar instructions; the boolean results are formed
+// exactly as above (NaNs included), only without control flow.
 template <typename T>
-__device__ __forceinline__ bool tri_test(const TriRec &r, V3 o, V3 d, T t_to, float &t, float &u, float &v) {
-  return tri_test<T>(mk(r.p0[0], r.p0[1], r.p0[2]), mk(r.e1[0], r.e1[1], r.e1[2]), mk(r.e2[0], r.e2[1], r.e2[2]), o,
-                     d, t_to, t, u, v);
+__device__ __forceinline__ bool tri_test_flat(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to, float &t, float &u,
+                                              float &v) {
+  V3 pvec = cross3(d, e2);
+  float det = dot3(e1, pvec);
+  bool ok = !(fabsf(det) < DET_EPS_F);
+  float inv = 1.0f / det;
+  V3 tvec = o - p0;
+  u = dot3(tvec, pvec) * inv;
+  ok = ok & !((u < 0.0f) | (u > 1.0f));
+  V3 qvec = cross3(tvec, e1);
+  v = dot3(d, qvec) * inv;
+  ok = ok & !((v < 0.0f) | (u + v > 1.0f));
+  t = dot3(e2, qvec) * inv;
+  ok = ok & ((T_FROM_F <= t) & ((T)t <= t_to));
+  return ok;
+}
+
+// World-list triangle records are read through the constant address space: a
+// wave-uniform address there always selects scalar loads (one s_load_dwordx16 per
+// record into SGPRs) instead of per-lane vector loads.
+#define RT_CONSTANT __attribute__((address_space(4)))
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 load_hot_tri(const HotTri *base, int idx) {
+  return *(const RT_CONSTANT f32x16 *)(uintptr_t)(base + idx);
+}
+__device__ __forceinline__ f32x8 load_sphere(const SphereRec *base, int idx) {
+  return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
+}
+__device__ __forceinline__ i32x4 load_run(const Run *base, int idx) {
+  return *(const RT_CONSTANT i32x4 *)(uintptr_t)(base + idx);
 }
 
 // bvh.cu:6-30 — "the segment crosses the box surface"; a box that wholly
@@ -228,7 +263,9 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
   }
 
   for (int ri = 0; ri < sc.n_runs; ri++) {
-    const Run run = sc.runs[ri];
+    const i32x4 rv = load_run(sc.runs, ri);
+    Run run;
+    run.kind = rv[0], run.first = rv[1], run.count = rv[2], run.pad = 0;
     if (run.kind == RUN_SKY) {
       // sky.cu:18-27: t = 1e9; t_from <= 1e9 always holds
       const T ts = (T)1e9f;
@@ -238,33 +275,65 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
       t_to = acc ? ts : t_to;
       win = acc ? make_id(RUN_SKY, 0) : win;
     }
-    if ((F & F_PGRAM) && run.kind == RUN_PGRAM) {
+    if ((F & F_TRIS) && run.kind == RUN_TRIS) {
+      // Records come in (first, second) pairs: a Parallelogram's two triangles, or a lone
+      // Triangle followed by an inert record.  Two SGPR buffers ping-pong: while record A
+      // is tested the fetch of B is in flight, and vice versa.  Scalar-memory waits are
+      // all-or-nothing (lgkmcnt counts SMEM out of order), so the order is pinned: wait
+      // for the buffer about to be used, only then issue the next fetch, then test.
+      const HotTri *base = sc.tris + run.first;
+      f32x16 A = load_hot_tri(base, 0);
       for (int i = 0; i < run.count; i++) {
-        const PgramRec &pg = sc.pgrams[run.first + i];
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): A has landed
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 B = load_hot_tri(base, 2 * i + 1);
+        __builtin_amdgcn_sched_barrier(0);
         float t = 0.f, u = 0.f, v = 0.f;
-        uint32_t id = make_id(RUN_PGRAM, run.first + i);
-        bool hit = tri_test<T>(pg.a, o, d, t_to, t, u, v);
-        if (!hit) {  // parallelogram.cu:33: second triangle only when the first missed
-          hit = tri_test<T>(pg.b, o, d, t_to, t, u, v);
-          id |= ID_SECOND;
+        const bool hit_a = tri_test_flat<T>(mk(A[0], A[1], A[2]), mk(A[3], A[4], A[5]), mk(A[6], A[7], A[8]), o, d,
+                                            t_to, t, u, v);
+        {
+          bool acc = hit_a && (!ok || (T)t < t_to);
+          ok = ok || acc;
+          t_to = acc ? (T)t : t_to;
+          win = acc ? make_id(RUN_TRIS, run.first + 2 * i) : win;
+          if (F & F_TEX) {
+            bu = acc ? u : bu;
+            bv = acc ? v : bv;
+          }
         }
-        bool acc = hit && (!ok || (T)t < t_to);
-        ok = ok || acc;
-        t_to = acc ? (T)t : t_to;
-        win = acc ? id : win;
-        if (F & F_TEX) {
-          bu = acc ? u : bu;
-          bv = acc ? v : bv;
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // B has landed
+        __builtin_amdgcn_sched_barrier(0);
+        A = load_hot_tri(base, 2 * i + 2);  // next pair (or the inert padding pair)
+        __builtin_amdgcn_sched_barrier(0);
+        if (__float_as_int(B[13]) & TRI_SECOND) {  // wave-uniform: a lone Triangle has no second record
+          // parallelogram.cu:33: the second triangle is tried only when the first missed
+          bool hit_b = tri_test_flat<T>(mk(B[0], B[1], B[2]), mk(B[3], B[4], B[5]), mk(B[6], B[7], B[8]), o, d, t_to,
+                                        t, u, v);
+          hit_b = hit_b && !hit_a;
+          bool acc = hit_b && (!ok || (T)t < t_to);
+          ok = ok || acc;
+          t_to = acc ? (T)t : t_to;
+          win = acc ? make_id(RUN_TRIS, run.first + 2 * i + 1) : win;
+          if (F & F_TEX) {
+            bu = acc ? u : bu;
+            bv = acc ? v : bv;
+          }
         }
       }
     }
     if ((F & F_SPHERE) && run.kind == RUN_SPHERE) {
+      f32x8 nxt = load_sphere(sc.spheres, run.first);
       for (int i = 0; i < run.count; i++) {
-        const SphereRec &sr = sc.spheres[run.first + i];
-        V3 oc = o - mk(sr.cx, sr.cy, sr.cz);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the triangle loop
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x8 cur = nxt;
+        nxt = load_sphere(sc.spheres, run.first + i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double r2 = __hiloint2double(__float_as_int(cur[7]), __float_as_int(cur[6]));
+        V3 oc = o - mk(cur[0], cur[1], cur[2]);
         double b = (double)(2.0f * dot3(d, oc));
         float lc = len3(oc);
-        double c = (double)(lc * lc) - sr.r2;
+        double c = (double)(lc * lc) - r2;
         double disc = b * b - 4 * sa * c;
         bool hit = false;
         double t = 0.0;
@@ -281,21 +350,6 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
         ok = ok || acc;
         t_to = acc ? (T)t : t_to;
         win = acc ? make_id(RUN_SPHERE, run.first + i) : win;
-      }
-    }
-    if ((F & F_TRI) && run.kind == RUN_TRI) {
-      for (int i = 0; i < run.count; i++) {
-        const TriangleRec &tr = sc.tris[run.first + i];
-        float t = 0.f, u = 0.f, v = 0.f;
-        bool hit = tri_test<T>(tr.a, o, d, t_to, t, u, v);
-        bool acc = hit && (!ok || (T)t < t_to);
-        ok = ok || acc;
-        t_to = acc ? (T)t : t_to;
-        win = acc ? make_id(RUN_TRI, run.first + i) : win;
-        if (F & F_TEX) {
-          bu = acc ? u : bu;
-          bv = acc ? v : bv;
-        }
       }
     }
     if ((F & F_BVH) && run.kind == RUN_BVH) {
@@ -357,20 +411,35 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
 }
 
 // ================================================================== trace kernel
+// Dynamic LDS: [ material records: lds_mats * 32 B ][ id stack: max_depth * blockDim entries ]
+// The id stack is laid out [depth][thread] so the lanes of a wave touch consecutive
+// bytes; entries are uint8 when every material id fits, else uint16 (lc.wide_ids).
+struct LaunchCfg {
+  int32_t lds_mats;    // materials staged in LDS (0: read them from global memory)
+  int32_t wide_ids;    // 1: uint16 stack entries
+  int32_t stack_off;   // byte offset of the id stack inside dynamic LDS
+  int32_t pad;
+};
+
 template <uint32_t F>
-__global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, uint32_t *__restrict__ states,
-                                                      float *__restrict__ out, uint32_t *__restrict__ ray_counts,
+__global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+                                                      uint32_t *__restrict__ states, float *__restrict__ out,
+                                                      uint32_t *__restrict__ ray_counts,
                                                       unsigned long long *__restrict__ counters) {
-  __shared__ MatRec s_mats[kLdsMats];
-  const bool mats_in_lds = sc.n_mats <= kLdsMats;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
+  uint8_t *stack8 = smem + lc.stack_off;
+  uint16_t *stack16 = reinterpret_cast<uint16_t *>(smem + lc.stack_off);
+  const bool mats_in_lds = lc.lds_mats > 0;
   if (mats_in_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_mats);
-    for (int w = threadIdx.x; w < sc.n_mats * 8; w += blockDim.x) dst[w] = src[w];
+    for (int w = threadIdx.x; w < lc.lds_mats * 8; w += blockDim.x) dst[w] = src[w];
   }
   __syncthreads();
 
   const int64_t n_items = fr.items;
+  const int tid = threadIdx.x, nthr = blockDim.x;
   // per-lane pixel state
   int64_t q = 0;
   int pi = 0, pj = 0, k = 0;
@@ -382,9 +451,13 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, u
   // per-lane path state
   V3 o = splat(0.f), d = splat(0.f);
   int depth = 0;
-  // Layer::attenuation stack (ray_tracing.cuh:9-15).  Layer::emitted is 0 for every
-  // material that scatters (only DiffuseLight and Sky emit, and neither scatters).
-  float att[RTMI_KERNEL_MAX_DEPTH * 3];
+  // Layer stack of ray_tracing.cuh:9-15.  Layer::emitted is 0 for every material that
+  // scatters (only DiffuseLight and Sky emit, and neither scatters), so a layer is its
+  // attenuation.  Without image textures the attenuation is the material's constant
+  // colour and the layer is stored as a material id in LDS; with image textures the
+  // sampled colour itself is kept (private memory).
+  constexpr int kAttFloats = (F & F_TEX) ? RTMI_KERNEL_MAX_DEPTH * 3 : 3;
+  float att[kAttFloats];
 
   for (;;) {
     // -------------------------------------------------------- sample / pixel bookkeeping
@@ -483,30 +556,26 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, u
           V3 nrm = splat(0.f);
           int mat = 0;
           float tu = 0.f, tv = 0.f;  // record.u, record.v (only read by image textures)
-          if ((F & F_PGRAM) && kind == RUN_PGRAM) {
-            const PgramRec &pg = sc.pgrams[index];
-            const bool second = (h.win & ID_SECOND) != 0;
-            const float *nn = second ? pg.b.n : pg.a.n;
-            V3 n = mk(nn[0], nn[1], nn[2]);
+          if ((F & F_TRIS) && kind == RUN_TRIS) {
+            const HotTri &tr = sc.tris[index];  // per-lane gather of the winner (L1/L2 resident)
+            V3 n = mk(tr.n[0], tr.n[1], tr.n[2]);
             nrm = dot3(d, n) < 0.f ? n : -n;  // utils.cu:80
-            mat = pg.mat;
-            if (F & F_TEX) {  // parallelogram.cu:26-29,35-38
-              float w = (float)((1.0 - (double)h.u) - (double)h.v);
-              if (!second) {
-                tu = (0.f * w + 1.f * h.u) + 0.f * h.v;
-                tv = (1.f * w + 1.f * h.u) + 0.f * h.v;
+            mat = tr.mat;
+            if (F & F_TEX) {
+              const int flags = tr.flags;
+              if (flags & TRI_PGRAM) {  // parallelogram.cu:26-29,35-38
+                float w = (float)((1.0 - (double)h.u) - (double)h.v);
+                if (!(flags & TRI_SECOND)) {
+                  tu = (0.f * w + 1.f * h.u) + 0.f * h.v;
+                  tv = (1.f * w + 1.f * h.u) + 0.f * h.v;
+                } else {
+                  tu = (1.f * w + 0.f * h.u) + 1.f * h.v;
+                  tv = (1.f * w + 0.f * h.u) + 0.f * h.v;
+                }
               } else {
-                tu = (1.f * w + 0.f * h.u) + 1.f * h.v;
-                tv = (1.f * w + 0.f * h.u) + 0.f * h.v;
+                tu = h.u, tv = h.v;  // triangle.cu:13
               }
             }
-          }
-          if ((F & F_TRI) && kind == RUN_TRI) {
-            const TriangleRec &tr = sc.tris[index];
-            V3 n = mk(tr.a.n[0], tr.a.n[1], tr.a.n[2]);
-            nrm = dot3(d, n) < 0.f ? n : -n;
-            mat = tr.mat;
-            tu = h.u, tv = h.v;  // triangle.cu:13
           }
           if ((F & F_SPHERE) && kind == RUN_SPHERE) {
             const SphereRec &sr = sc.spheres[index];
@@ -577,9 +646,15 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, u
               scattered = !(zero || nan);
             }
             if (scattered) {
-              att[depth * 3 + 0] = rgb.x;
-              att[depth * 3 + 1] = rgb.y;
-              att[depth * 3 + 2] = rgb.z;
+              if (F & F_TEX) {
+                att[depth * 3 + 0] = rgb.x;
+                att[depth * 3 + 1] = rgb.y;
+                att[depth * 3 + 2] = rgb.z;
+              } else if (lc.wide_ids) {
+                stack16[depth * nthr + tid] = (uint16_t)mat;
+              } else {
+                stack8[depth * nthr + tid] = (uint8_t)mat;
+              }
               depth++;
               o = p;
               d = unit3(nd);  // Ray's constructor
@@ -591,8 +666,18 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, u
       if (ended) {
         // ray_tracing.cu:50-52 with emitted == 0 on every stored layer
         for (int i = depth - 1; i >= 0; i--) {
-          result = mk(0.f + att[i * 3 + 0] * result.x, 0.f + att[i * 3 + 1] * result.y,
-                      0.f + att[i * 3 + 2] * result.z);
+          V3 a;
+          if (F & F_TEX) {
+            a = mk(att[i * 3 + 0], att[i * 3 + 1], att[i * 3 + 2]);
+          } else {
+            const int mi = lc.wide_ids ? (int)stack16[i * nthr + tid] : (int)stack8[i * nthr + tid];
+            if (mats_in_lds) {
+              a = mk(s_mats[mi].r, s_mats[mi].g, s_mats[mi].b);
+            } else {
+              a = mk(sc.mats[mi].r, sc.mats[mi].g, sc.mats[mi].b);
+            }
+          }
+          result = mk(0.f + a.x * result.x, 0.f + a.y * result.y, 0.f + a.z * result.z);
         }
         color = color + result;
         active = false;
@@ -636,29 +721,45 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
   return hipGetLastError();
 }
 
+static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
+  LaunchCfg lc{};
+  lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
+  lc.wide_ids = sc.n_mats > 256 ? 1 : 0;
+  size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
+  lc.stack_off = (int32_t)off;
+  size_t stack = (variant & F_TEX) ? 0 : (size_t)(fr.max_depth > 0 ? fr.max_depth : 1) * threads * (lc.wide_ids ? 2 : 1);
+  *lds_bytes = off + stack;
+  return lc;
+}
+
 template <uint32_t F>
 static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                                   uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
                                   hipStream_t stream) {
-  hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), 0, stream, sc, fr, d_states, d_out, d_ray_counts,
-                     d_counters);
+  size_t lds = 0;
+  LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
+  hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
+                     d_ray_counts, d_counters);
   return hipGetLastError();
 }
 
 template <uint32_t F>
-static int occupancy_t(int threads) {
+static int occupancy_t(const SceneDev &sc, const FrameDev &fr, int threads) {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<F>, threads, 0) != hipSuccess) nb = 0;
+  size_t lds = 0;
+  (void)make_cfg(F, sc, fr, threads, &lds);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<F>, threads, lds) != hipSuccess) nb = 0;
   return nb;
 }
 
-// The specialisations that are instantiated; features outside them fall back to F_ALL.
+// The specialisations that are instantiated; a feature set outside them uses F_ALL.
 #define RTMI_FOR_EACH_VARIANT(X)                     \
   X(0u)                                              \
-  X(F_PGRAM)                                         \
+  X(F_TRIS)                                          \
   X(F_SPHERE)                                        \
-  X(F_PGRAM | F_BVH)                                 \
-  X(F_PGRAM | F_SPHERE | F_TEX)                      \
+  X(F_TRIS | F_SPHERE)                               \
+  X(F_TRIS | F_BVH)                                  \
+  X(F_TRIS | F_SPHERE | F_TEX)                       \
   X(F_ALL)
 
 uint32_t pick_variant(uint32_t features) {
@@ -669,9 +770,9 @@ uint32_t pick_variant(uint32_t features) {
   return F_ALL;
 }
 
-int render_occupancy(uint32_t variant, int threads) {
+int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads) {
 #define X(V) \
-  if (variant == (uint32_t)(V)) return occupancy_t<(V)>(threads);
+  if (variant == (uint32_t)(V)) return occupancy_t<(V)>(sc, fr, threads);
   RTMI_FOR_EACH_VARIANT(X)
 #undef X
   return 0;

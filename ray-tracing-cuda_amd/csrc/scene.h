@@ -59,8 +59,8 @@ struct Scene {
   uint32_t features = 0;
   std::vector<Run> runs;
   std::vector<SphereRec> spheres;
-  std::vector<PgramRec> pgrams;
-  std::vector<TriangleRec> tris;
+  std::vector<HotTri> tris;
+  int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;
   std::vector<BvhNode> nodes;
   std::vector<FaceRec> faces;

@@ -21,14 +21,20 @@ TriRec make_tri(V3 p0, V3 p1, V3 p2) {
   return r;
 }
 
+static HotTri hot_tri(V3 p0, V3 p1, V3 p2, int mat, int flags) {
+  TriRec t = make_tri(p0, p1, p2);
+  HotTri h{};
+  for (int c = 0; c < 3; c++) h.p0[c] = t.p0[c], h.e1[c] = t.e1[c], h.e2[c] = t.e2[c], h.n[c] = t.n[c];
+  h.mat = mat;
+  h.flags = flags;
+  return h;
+}
+
 // parallelogram.cu:10-15 + the two triangles of parallelogram.cu:25,33
-static PgramRec make_pgram(V3 p0, V3 p1, V3 p2, int mat) {
+static void push_pgram(std::vector<HotTri> &out, V3 p0, V3 p1, V3 p2, int mat) {
   V3 p3 = p1 + p2 - p0;
-  PgramRec r{};
-  r.a = make_tri(p0, p1, p2);
-  r.b = make_tri(p1, p2, p3);
-  r.mat = mat;
-  return r;
+  out.push_back(hot_tri(p0, p1, p2, mat, TRI_PGRAM));
+  out.push_back(hot_tri(p1, p2, p3, mat, TRI_PGRAM | TRI_SECOND));
 }
 
 // parallelepiped.cu:8-18: derive the four opposite corners.
@@ -132,9 +138,10 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, const std::vector<FacePt
 }
 
 std::string Scene::flatten() {
-  runs.clear(), spheres.clear(), pgrams.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), faces.clear(),
+  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), faces.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
+  n_pgrams = n_triangles = n_spheres = 0;
   if (!has_camera) return "scene has no camera";
   if (world.size() > 1024) return "world exceeds HitableList::kMaxHitables (1024)";
   if (cam.defocus) features |= F_DEFOCUS;
@@ -163,8 +170,10 @@ std::string Scene::flatten() {
     mat_recs.push_back(r);
   }
 
+  // Run::count is in records for spheres / BVHs and in record PAIRS for RUN_TRIS.
   auto push_run = [&](int kind, int first) {
-    if (!runs.empty() && runs.back().kind == kind && runs.back().first + runs.back().count == first) {
+    const int stride = kind == RUN_TRIS ? 2 : 1;
+    if (!runs.empty() && runs.back().kind == kind && runs.back().first + stride * runs.back().count == first) {
       runs.back().count++;
     } else {
       runs.push_back(Run{kind, first, 1, 0});
@@ -193,20 +202,20 @@ std::string Scene::flatten() {
       }
       case OBJ_TRI: {
         if (!check_mat(ob.mat)) return "triangle without a valid material";
-        TriangleRec r{};
-        r.a = make_tri(ob.p[0], ob.p[1], ob.p[2]);
-        r.mat = ob.mat;
-        tris.push_back(r);
-        push_run(RUN_TRI, (int)tris.size() - 1);
-        features |= F_TRI;
+        tris.push_back(hot_tri(ob.p[0], ob.p[1], ob.p[2], ob.mat, 0));
+        tris.push_back(HotTri{});  // inert second record: the world-list loop walks pairs
+        push_run(RUN_TRIS, (int)tris.size() - 2);
+        features |= F_TRIS;
+        n_triangles++;
         bytes_per_ray += 40;
         break;
       }
       case OBJ_PGRAM: {
         if (!check_mat(ob.mat)) return "parallelogram without a valid material";
-        pgrams.push_back(make_pgram(ob.p[0], ob.p[1], ob.p[2], ob.mat));
-        push_run(RUN_PGRAM, (int)pgrams.size() - 1);
-        features |= F_PGRAM;
+        push_pgram(tris, ob.p[0], ob.p[1], ob.p[2], ob.mat);
+        push_run(RUN_TRIS, (int)tris.size() - 2);
+        features |= F_TRIS;
+        n_pgrams++;
         bytes_per_ray += 40;
         break;
       }
@@ -217,12 +226,13 @@ std::string Scene::flatten() {
           const V3 *c = ob.p + set * 4;
           for (int i = 1; i <= 3; i++) {
             int x = i, y = (i + 1 == 4) ? 1 : x + 1;
-            pgrams.push_back(make_pgram(c[0], c[x], c[y], ob.mat));
-            push_run(RUN_PGRAM, (int)pgrams.size() - 1);
+            push_pgram(tris, c[0], c[x], c[y], ob.mat);
+            push_run(RUN_TRIS, (int)tris.size() - 2);
+            n_pgrams++;
             bytes_per_ray += 40;
           }
         }
-        features |= F_PGRAM;
+        features |= F_TRIS;
         break;
       }
       case OBJ_BVH: {
@@ -266,6 +276,14 @@ std::string Scene::flatten() {
     }
   }
   if (!face_uv.empty()) face_uv.resize(faces.size() * 6, 0.f);
+  if (!tris.empty()) {  // prefetch target past the last pair (fetched, never tested)
+    tris.push_back(HotTri{});
+    tris.push_back(HotTri{});
+  }
+  n_spheres = (int)spheres.size();
+  if (!spheres.empty()) spheres.push_back(SphereRec{});  // same for the sphere look-ahead
+  for (const MatRec &m : mat_recs)
+    if (m.tex >= 0) bytes_per_ray += 4;  // one RGBA8 texel per textured hit
   return "";
 }
 

@@ -18,7 +18,7 @@
 
 namespace rtmi {
 
-enum RunKind : int32_t { RUN_SKY = 0, RUN_SPHERE = 1, RUN_PGRAM = 2, RUN_TRI = 3, RUN_BVH = 4 };
+enum RunKind : int32_t { RUN_SKY = 0, RUN_SPHERE = 1, RUN_TRIS = 2, RUN_BVH = 4 };
 
 // A maximal stretch of consecutive world-list entries of one kind, in list
 // order (order carries the tie rule of HitableList::Hit, hitable_list.cu:18).
@@ -40,16 +40,18 @@ struct TriRec {  // 48 B: Moller-Trumbore operands that do not depend on the ray
   float n[3];   // normalize(cross(e1, e2))   (utils.cu:79)
 };
 
-struct PgramRec {  // 128 B: triangles (p0,p1,p2) and (p1,p2,p3), parallelogram.cu:25,33
-  TriRec a, b;
+// One triangle of the world list, 64 B = one s_load_dwordx16.  A Parallelogram is two
+// consecutive records, (p0,p1,p2) then (p1,p2,p3) with TRI_SECOND set: the second is
+// tested only by lanes whose first test missed (parallelogram.cu:25,33).
+enum : int32_t { TRI_SECOND = 1, TRI_PGRAM = 2 };
+struct HotTri {
+  float p0[3];
+  float e1[3];
+  float e2[3];
+  float n[3];
   int32_t mat;
-  int32_t pad[7];
-};
-
-struct TriangleRec {  // 64 B
-  TriRec a;
-  int32_t mat;
-  int32_t pad[3];
+  int32_t flags;
+  int32_t pad[2];
 };
 
 enum MatKind : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_SKY = 4 };
@@ -96,13 +98,12 @@ struct CameraDev {
   int32_t defocus;
 };
 
-constexpr int kLdsMats = 512;  // material records staged in LDS (16 KiB)
+constexpr int kLdsMats = 512;  // at most this many material records are staged in LDS
 
 struct SceneDev {
   const Run *runs;
   const SphereRec *spheres;
-  const PgramRec *pgrams;
-  const TriangleRec *tris;
+  const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
   const BvhRec *bvhs;
   const BvhNode *nodes;
   const FaceRec *faces;
@@ -116,12 +117,11 @@ struct SceneDev {
 // Feature bits selecting a kernel specialisation.
 enum : uint32_t {
   F_SPHERE = 1u,   // double-precision t
-  F_PGRAM = 2u,
-  F_TRI = 4u,
+  F_TRIS = 2u,    // parallelograms / boxes / triangles in the world list
   F_BVH = 8u,
   F_TEX = 16u,     // some material reads an image texture (u,v needed)
   F_DEFOCUS = 32u,
-  F_ALL = 63u
+  F_ALL = 59u
 };
 
 struct FrameDev {
