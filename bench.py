@@ -167,6 +167,15 @@ def main():
         rays_all = float(rays_rank)
 
     if rank == 0:
+        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot
+        # run inside this process); scaled by this run's ray count, scene must match.
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            if tj.get("workload_scene") == args.scene:
+                traffic = tj["hbm_bytes_per_ray"] * rays_rank
+        except (OSError, ValueError, KeyError):
+            pass
         value = rays_all * args.steps / dt / 1e6
         achieved = rays_rank * bytes_per_ray / (kern_ms * 1e-3) / 1e9  # GB/s, dominant kernel on this rank
         out = {
@@ -180,7 +189,7 @@ def main():
                 "bytes_per_ray": bytes_per_ray, "kernel_ms": kern_ms,
             },
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.scene, seed)

@@ -220,16 +220,20 @@ __device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) {
 }
 
 // lambertian.cu:19-31 / metal.cu:27-36: rejection-sample the unit ball.
-// l = (float)pow((double)(x*x+y*y+z*z), 0.5) == sqrtf(sum) (double rounding of
-// a square root of a binary32 value is innocuous).
-__device__ __forceinline__ V3 ball_sample(Rng &rng, float &l) {
+// l = (float)pow((double)(x*x+y*y+z*z), 0.5) == sqrtf(sum) (double rounding of a square
+// root of a binary32 value is innocuous).  The loop condition `l > 1` is decided without
+// the square root: sqrtf is monotone, sqrtf(1 + 2^-23) rounds to exactly 1 and
+// sqrtf(1 + 2^-22) to 1 + 2^-23, so sqrtf(s) > 1  <=>  s > 1 + 2^-23
+// (tests/test_host_logic.py::test_rejection_threshold).  Returns the accepted sum.
+#define BALL_S_MAX 1.00000011920928955078125f /* 1 + 2^-23 */
+__device__ __forceinline__ V3 ball_sample(Rng &rng, float &sum) {
   float x, y, z;
   do {
     x = rng_range(-1.f, 1.f, rng);
     y = rng_range(-1.f, 1.f, rng);
     z = rng_range(-1.f, 1.f, rng);
-    l = sqrtf(x * x + y * y + z * z);
-  } while (l > 1.f);
+    sum = x * x + y * y + z * z;
+  } while (sum > BALL_S_MAX);
   return mk(x, y, z);
 }
 
@@ -440,6 +444,8 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
 
   const int64_t n_items = fr.items;
   const int tid = threadIdx.x, nthr = blockDim.x;
+  const bool w_pow2 = (fr.width & (fr.width - 1)) == 0, h_pow2 = (fr.height & (fr.height - 1)) == 0;
+  const double inv_w = 1.0 / (double)fr.width, inv_h = 1.0 / (double)fr.height;
   // per-lane pixel state
   int64_t q = 0;
   int pi = 0, pj = 0, k = 0;
@@ -512,8 +518,11 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
         // ray_tracing.cu:68-74 + camera.cu:57-70
         float r1 = rng_range(0.f, 1.f, rng);
         float r2 = rng_range(0.f, 1.f, rng);
-        double x = ((double)r1 + (double)pj) / (double)fr.width;
-        double y = ((double)r2 + (double)(fr.height - pi)) / (double)fr.height;
+        // division by a power of two is an exact scaling: multiply by the (exact) reciprocal
+        double x = (double)r1 + (double)pj;
+        double y = (double)r2 + (double)(fr.height - pi);
+        x = w_pow2 ? x * inv_w : x / (double)fr.width;
+        y = h_pow2 ? y * inv_h : y / (double)fr.height;
         x = 2 * x - 1;
         y = 2 * y - 1;
         x = (x + 1) / 2;
@@ -618,8 +627,9 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
             bool scattered = false;
             if (m.kind == MAT_LAMBERTIAN) {  // lambertian.cu:33-43
               if (!(dn >= 0.f)) {
-                float l;
-                V3 s = ball_sample(rng, l);
+                float sum;
+                V3 s = ball_sample(rng, sum);
+                const float l = sqrtf(sum);
                 s = mk(s.x / l, s.y / l, s.z / l);
                 nd = unit3(s + nrm);
                 scattered = true;
@@ -628,8 +638,8 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
               if (!(dn >= 0.f)) {
                 V3 refl = reflect3(d, nrm);
                 if (m.param > 0.f) {
-                  float l;
-                  V3 s = ball_sample(rng, l);
+                  float sum;
+                  V3 s = ball_sample(rng, sum);
                   nd = refl + m.param * s;
                 } else {
                   nd = refl;

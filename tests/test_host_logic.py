@@ -39,6 +39,19 @@ def test_float_thresholds_used_by_the_kernel():
     assert float(f(1e9)) == 1e9  # Sky's t is exact in binary32 (sky.cu:20)
 
 
+def test_rejection_threshold():
+    """kernels.hip decides the rejection loop `sqrtf(s) > 1` (lambertian.cu:25-26) as
+    `s > 1 + 2^-23`: check the equivalence on every binary32 in a window around 1 and on a
+    random sample of the whole range [0, 3]."""
+    f = np.float32
+    thr = np.nextafter(f(1), f(2))
+    xs = np.arange(0x3f7f0000, 0x3f810000, dtype=np.uint32).view(np.float32)
+    assert ((np.sqrt(xs) > 1) == (xs > thr)).all()
+    r = np.random.default_rng(0).uniform(0, 3, 1_000_000).astype(np.float32)
+    assert ((np.sqrt(r) > 1) == (r > thr)).all()
+    assert float(thr) == 1.00000011920928955078125
+
+
 @pytest.mark.parametrize("h,w", [(8, 8), (20, 30), (37, 53), (64, 64), (1, 1), (9, 200)])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_tile_shards_partition_the_frame(h, w, world):
