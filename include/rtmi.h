@@ -100,6 +100,9 @@ int rtmi_add_parallelepiped(rtmi_scene *s, const float p[12], int material);    
 typedef void (*rtmi_transform_fn)(const float in[3], float out[3], void *user);
 int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int material,
                                     rtmi_transform_fn transform, void *user);                   /* parallelepiped.cu:34-55 */
+/* A Parallelepiped given as the six parallelograms AddCorner appended (3 points each, 54
+ * floats); used when the corners were derived elsewhere (device-side constructors). */
+int rtmi_add_parallelepiped_faces(rtmi_scene *s, const float faces[54], int material);          /* parallelepiped.cu:25-32 */
 int rtmi_add_sky(rtmi_scene *s);                                                                /* sky.cu:16 */
 /* BVH<Face<HasTexCoord>,AABB>(faces, n, material) (bvh.cuh:170-173).  faces:
  * n*9 floats; uvs: n*6 floats or NULL (Face<false>); material < 0 keeps
@@ -115,6 +118,9 @@ int rtmi_camera_raw(rtmi_scene *s, const float pos[3], const float lower_left[3]
                     const float vertical[3]);                                                    /* camera.cu:40-47 */
 /* position, lower_left_corner, horizontal, vertical, u, v, w (21 floats) */
 int rtmi_camera_get(const rtmi_scene *s, float out[21]);
+/* Install a camera whose frame was computed elsewhere (a Camera constructed on the device):
+ * the same 21 floats, is_defocus_camera_ and lens_radius_ (camera.cuh:12-14). */
+int rtmi_camera_set(rtmi_scene *s, const float frame[21], int is_defocus, double lens_radius);
 
 /* Flatten the recorded graph into the device layout and upload it to the
  * current HIP device.  Synchronous.  Replaces the point in Main where

@@ -189,9 +189,10 @@ int rtmi_add_parallelepiped(rtmi_scene *s, const float p[12], int material) {
   if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelepiped arguments");
   HostObj o{};
   o.kind = OBJ_BOX, o.mat = material;
-  V3 c[4];
+  V3 c[4], corners[8];
   for (int i = 0; i < 4; i++) c[i] = v3(p + 3 * i);
-  box_from_points(c, o.p);
+  box_from_points(c, corners);
+  box_faces(corners, o.p);
   return append(s, o);
 }
 int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int material, rtmi_transform_fn transform,
@@ -206,13 +207,22 @@ int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int m
   for (int i = 1; i <= 3; i++) q[i][i - 1] = 0;
   HostObj o{};
   o.kind = OBJ_BOX, o.mat = material;
+  V3 corners[8];
   for (int i = 0; i < 4; i++) {
     float t[3];
     transform(p[i], t, user);
-    o.p[i] = v3(t);
+    corners[i] = v3(t);
     transform(q[i], t, user);
-    o.p[4 + i] = v3(t);
+    corners[4 + i] = v3(t);
   }
+  box_faces(corners, o.p);
+  return append(s, o);
+}
+int rtmi_add_parallelepiped_faces(rtmi_scene *s, const float faces[54], int material) {
+  if (!s || !faces || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelepiped arguments");
+  HostObj o{};
+  o.kind = OBJ_BOX, o.mat = material;
+  for (int i = 0; i < 18; i++) o.p[i] = v3(faces + 3 * i);
   return append(s, o);
 }
 int rtmi_add_sky(rtmi_scene *s) {
@@ -251,6 +261,18 @@ int rtmi_camera_defocus(rtmi_scene *s, const float pos[3], const float look_at[3
 int rtmi_camera_raw(rtmi_scene *s, const float pos[3], const float llc[3], const float horiz[3], const float vert[3]) {
   if (!s || !pos || !llc || !horiz || !vert) return fail(RTMI_ERR_INVALID, "null argument");
   camera_raw(*S(s), v3(pos), v3(llc), v3(horiz), v3(vert));
+  S(s)->committed = false;
+  return RTMI_OK;
+}
+int rtmi_camera_set(rtmi_scene *s, const float f[21], int is_defocus, double lens_radius) {
+  if (!s || !f) return fail(RTMI_ERR_INVALID, "null argument");
+  CameraDev &c = S(s)->cam;
+  c.position = v3(f), c.llc = v3(f + 3), c.horizontal = v3(f + 6), c.vertical = v3(f + 9);
+  c.u = v3(f + 12), c.v = v3(f + 15);
+  S(s)->cam_w = v3(f + 18);
+  c.defocus = is_defocus ? 1 : 0;
+  c.lens_radius = (float)lens_radius;  // DiskRand(float radius), camera.cu:64,74
+  S(s)->has_camera = true;
   S(s)->committed = false;
   return RTMI_OK;
 }

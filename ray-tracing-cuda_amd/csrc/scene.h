@@ -34,7 +34,7 @@ enum ObjKind { OBJ_SPHERE, OBJ_TRI, OBJ_PGRAM, OBJ_BOX, OBJ_SKY, OBJ_BVH };
 struct HostObj {
   ObjKind kind;
   int mat = -1;
-  V3 p[8];            // sphere: p[0]=centre; tri/pgram: p[0..2]; box: corner sets p[0..3], q = p[4..7]
+  V3 p[18];           // sphere: p[0]=centre; tri/pgram: p[0..2]; box: six faces of three points
   double radius = 0;  // sphere
   int bvh = -1;       // index into Scene::bvhs
 };
@@ -82,5 +82,6 @@ void camera_pinhole(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspe
 void camera_defocus(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspect, double aperture, double focus);
 void camera_raw(Scene &s, V3 pos, V3 llc, V3 horiz, V3 vert);
 void box_from_points(const V3 p[4], V3 out[8]);
+void box_faces(const V3 corners[8], V3 faces[18]);
 
 }  // namespace rtmi

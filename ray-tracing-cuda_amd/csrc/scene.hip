@@ -48,6 +48,20 @@ void box_from_points(const V3 p[4], V3 out[8]) {
   for (int i = 0; i < 4; i++) out[i] = p[i], out[4 + i] = q[i];
 }
 
+// parallelepiped.cu:25-32: AddCorner(p) then AddCorner(q), faces (c0,c1,c2), (c0,c2,c3), (c0,c3,c1)
+void box_faces(const V3 corners[8], V3 faces[18]) {
+  int k = 0;
+  for (int set = 0; set < 2; set++) {
+    const V3 *c = corners + set * 4;
+    for (int i = 1; i <= 3; i++) {
+      int x = i, y = (i + 1 == 4) ? 1 : x + 1;
+      faces[k++] = c[0];
+      faces[k++] = c[x];
+      faces[k++] = c[y];
+    }
+  }
+}
+
 // camera.cu:24-38
 void camera_pinhole(Scene &s, V3 pos, V3 look_at, V3 up, double fov, double aspect) {
   CameraDev &c = s.cam;
@@ -221,16 +235,11 @@ std::string Scene::flatten() {
       }
       case OBJ_BOX: {
         if (!check_mat(ob.mat)) return "parallelepiped without a valid material";
-        // parallelepiped.cu:25-32: AddCorner(p) then AddCorner(q), three faces each
-        for (int set = 0; set < 2; set++) {
-          const V3 *c = ob.p + set * 4;
-          for (int i = 1; i <= 3; i++) {
-            int x = i, y = (i + 1 == 4) ? 1 : x + 1;
-            push_pgram(tris, c[0], c[x], c[y], ob.mat);
-            push_run(RUN_TRIS, (int)tris.size() - 2);
-            n_pgrams++;
-            bytes_per_ray += 40;
-          }
+        for (int fidx = 0; fidx < 6; fidx++) {  // the six faces in AddCorner order
+          push_pgram(tris, ob.p[fidx * 3], ob.p[fidx * 3 + 1], ob.p[fidx * 3 + 2], ob.mat);
+          push_run(RUN_TRIS, (int)tris.size() - 2);
+          n_pgrams++;
+          bytes_per_ray += 40;
         }
         features |= F_TRIS;
         break;

@@ -55,12 +55,14 @@ SYMBOLS = [
     ("rtmi_add_parallelogram", C.c_int, [C.c_void_p, _fp, C.c_int]),
     ("rtmi_add_parallelepiped", C.c_int, [C.c_void_p, _fp, C.c_int]),
     ("rtmi_add_parallelepiped_lengths", C.c_int, [C.c_void_p, _fp, C.c_int, TRANSFORM_FN, C.c_void_p]),
+    ("rtmi_add_parallelepiped_faces", C.c_int, [C.c_void_p, _fp, C.c_int]),
     ("rtmi_add_sky", C.c_int, [C.c_void_p]),
     ("rtmi_add_bvh", C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int]),
     ("rtmi_camera_pinhole", C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double]),
     ("rtmi_camera_defocus", C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double]),
     ("rtmi_camera_raw", C.c_int, [C.c_void_p, _fp, _fp, _fp, _fp]),
     ("rtmi_camera_get", C.c_int, [C.c_void_p, _fp]),
+    ("rtmi_camera_set", C.c_int, [C.c_void_p, _fp, C.c_int, C.c_double]),
     ("rtmi_scene_commit", C.c_int, [C.c_void_p]),
     ("rtmi_scene_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("rtmi_scene_bytes_per_ray", C.c_int64, [C.c_void_p]),
