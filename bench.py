@@ -109,7 +109,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even with one rank
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.blocks_per_cu or args.threads:
         rtmi.lib().rtmi_set_launch(args.blocks_per_cu, args.threads)
@@ -131,7 +132,7 @@ def main():
         R.render()
         if ev:
             ev[1].record()
-        if world > 1:
+        if use_dist:
             allt = gather_to_root(R.tiles, 0)
             if rank == 0:
                 R.untile(allt)
@@ -141,13 +142,13 @@ def main():
     for _ in range(args.warmup):
         step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(events[i])
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -155,7 +156,7 @@ def main():
     rays_rank = R.total_rays()  # rays of one step on this rank (identical every step)
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
     tt = torch.tensor([dt, float(rays_rank), kern_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
@@ -194,7 +195,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.scene, seed)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

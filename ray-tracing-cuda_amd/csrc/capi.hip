@@ -314,6 +314,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->tris, &d.tris))) return rc;
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
+  if ((rc = upload(s, s->subnodes, &d.subnodes))) return rc;
   if ((rc = upload(s, s->faces, &d.faces))) return rc;
   if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;

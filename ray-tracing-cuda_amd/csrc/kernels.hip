@@ -357,6 +357,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
       }
     }
     if ((F & F_BVH) && run.kind == RUN_BVH) {
+      // Slab-test operands, once per ray (used only by the conservative sub-trees).
+      const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
         // bvh.cuh:123-158 as an explicit depth-first walk: the left subtree first,
@@ -376,22 +378,67 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
           const BvhNode nd = sc.nodes[ni];
           if (!first && !aabb_test<T>(nd, o, d, bt_to)) continue;
           first = false;
-          if (nd.right < 0) {
-            int cnt = -nd.right;
-            for (int fi = 0; fi < cnt; fi++) {
-              const FaceRec &fc = sc.faces[nd.left + fi];
-              float t = 0.f, u = 0.f, v = 0.f;
-              if (tri_test<T>(mk(fc.p0[0], fc.p0[1], fc.p0[2]), mk(fc.e1[0], fc.e1[1], fc.e1[2]),
-                              mk(fc.e2[0], fc.e2[1], fc.e2[2]), o, d, bt_to, t, u, v)) {
-                bt_to = (T)t;
-                bhit = true;
-                bface = nd.left + fi;
-                fu = u, fv = v;
-              }
-            }
-          } else {
+          if (nd.right >= 0) {
             stack[top++] = nd.right;
             stack[top++] = nd.left;
+            continue;
+          }
+          // ---- leaf query (bvh.cuh:125-136): among this leaf's faces accepted with
+          // t_from <= t <= bt_to keep the smallest t, the highest reference index among equal
+          // t — what the reference's in-order scan with `t <= t_to` ends with.  The faces are
+          // reached through a padded sub-tree instead of a scan of up to 2048 of them.
+          T best = bt_to;
+          bool have = false;
+          int best_face = 0, best_orig = -1;
+          float lu = 0.f, lv = 0.f;
+          int sstack[32];
+          int stop = 0;
+          sstack[stop++] = nd.left;
+          while (stop > 0) {
+            const BvhNode sn = sc.subnodes[sstack[--stop]];
+            // slab test with slack on both ends; NaNs (0 * inf) make a compare false -> visit
+            float lo = T_FROM_F * 0.999f, hi = (float)best * 1.0001f + 1e-6f;
+            const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv_d.x, inv_d.y, inv_d.z};
+            bool miss = false;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+              if (dd[a] == 0.f) {
+                miss = miss || (oo[a] < sn.mn[a]) || (oo[a] > sn.mx[a]);
+              } else {
+                float t0 = (sn.mn[a] - oo[a]) * ii[a], t1 = (sn.mx[a] - oo[a]) * ii[a];
+                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                lo = fmaxf(lo, tn - fabsf(tn) * 1e-5f);
+                hi = fminf(hi, tf + fabsf(tf) * 1e-5f);
+              }
+            }
+            if (miss || lo > hi) continue;
+            if (sn.right >= 0) {
+              sstack[stop++] = sn.right;
+              sstack[stop++] = sn.left;
+              continue;
+            }
+            const int cnt = -sn.right;
+            for (int fi = 0; fi < cnt; fi++) {
+              const FaceRec &fc = sc.faces[sn.left + fi];
+              float t = 0.f, u = 0.f, v = 0.f;
+              if (tri_test<T>(mk(fc.p0[0], fc.p0[1], fc.p0[2]), mk(fc.e1[0], fc.e1[1], fc.e1[2]),
+                              mk(fc.e2[0], fc.e2[1], fc.e2[2]), o, d, best, t, u, v)) {
+                const int orig = fc.orig;
+                if ((T)t < best || !have || orig > best_orig) {  // t <= best holds here
+                  best = (T)t;
+                  have = true;
+                  best_face = sn.left + fi;
+                  best_orig = orig;
+                  lu = u, lv = v;
+                }
+              }
+            }
+          }
+          if (have) {
+            bt_to = best;
+            bhit = true;
+            bface = best_face;
+            fu = lu, fv = lv;
           }
         }
         bool acc = bhit && (!ok || bt_to < t_to);
@@ -600,12 +647,13 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
           }
           if ((F & F_BVH) && kind == RUN_BVH) {
             const FaceRec &fc = sc.faces[index];
-            V3 n = mk(fc.n[0], fc.n[1], fc.n[2]);
+            // utils.cu:79: normalize(cross(v0v1, v0v2)), recomputed for the winning face only
+            V3 n = unit3(cross3(mk(fc.e1[0], fc.e1[1], fc.e1[2]), mk(fc.e2[0], fc.e2[1], fc.e2[2])));
             nrm = dot3(d, n) < 0.f ? n : -n;
             const BvhRec br = sc.bvhs[h.aux];
             mat = br.mat;
             if ((F & F_TEX) && br.has_uv) {  // bvh.cuh:41-45
-              const float *tc = sc.face_uv + (size_t)index * 6;
+              const float *tc = sc.face_uv + (size_t)(br.face_base + fc.orig) * 6;
               float w = (float)((1.0 - (double)h.u) - (double)h.v);
               tu = (tc[0] * w + tc[2] * h.u) + tc[4] * h.v;
               tv = (tc[1] * w + tc[3] * h.u) + tc[5] * h.v;

@@ -63,6 +63,7 @@ struct Scene {
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;
   std::vector<BvhNode> nodes;
+  std::vector<BvhNode> subnodes;
   std::vector<FaceRec> faces;
   std::vector<float> face_uv;
   std::vector<MatRec> mat_recs;

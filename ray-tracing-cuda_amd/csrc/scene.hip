@@ -116,15 +116,70 @@ void camera_raw(Scene &s, V3 pos, V3 llc, V3 horiz, V3 vert) {
 struct FacePts {
   V3 p[3];
   float uv[6];
+  int orig;
 };
+
+// Sub-tree over the faces [first, first+n) of one reference leaf.  Faces are reordered inside
+// the range (each keeps `orig`); bounds are padded so that no face the binary32 Moller-Trumbore
+// test can accept is ever culled by the (also slack) slab test of the kernel.  The answer of a
+// leaf query does not depend on visiting order: it is the accepted face with the smallest t, the
+// highest reference index among equal t (bvh.cuh:127-134 scans in order with `t <= t_to`).
+static int build_subtree(std::vector<BvhNode> &sub, std::vector<FacePts> &fp, int first, int n) {
+  BvhNode nd;
+  float cmn[3], cmx[3];
+  for (int k = 0; k < 3; k++) nd.mn[k] = cmn[k] = INFINITY, nd.mx[k] = cmx[k] = -INFINITY;
+  for (int i = 0; i < n; i++) {
+    float c[3] = {0, 0, 0};
+    for (int j = 0; j < 3; j++) {
+      const V3 &p = fp[first + i].p[j];
+      const float q[3] = {p.x, p.y, p.z};
+      for (int k = 0; k < 3; k++) {
+        nd.mn[k] = fminf(nd.mn[k], q[k]);
+        nd.mx[k] = fmaxf(nd.mx[k], q[k]);
+        c[k] += q[k];
+      }
+    }
+    for (int k = 0; k < 3; k++) cmn[k] = fminf(cmn[k], c[k]), cmx[k] = fmaxf(cmx[k], c[k]);
+  }
+  float diag = 0.f, mag = 0.f;
+  for (int k = 0; k < 3; k++) {
+    diag = fmaxf(diag, nd.mx[k] - nd.mn[k]);
+    mag = fmaxf(mag, fmaxf(fabsf(nd.mn[k]), fabsf(nd.mx[k])));
+  }
+  const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
+  for (int k = 0; k < 3; k++) nd.mn[k] -= pad, nd.mx[k] += pad;
+  const int me = (int)sub.size();
+  sub.push_back(nd);
+  if (n <= 4) {
+    sub[me].left = first;
+    sub[me].right = -n;
+    return me;
+  }
+  int axis = 0;
+  for (int k = 1; k < 3; k++)
+    if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+  auto key = [axis](const FacePts &f) {
+    const float a[3] = {f.p[0].x + f.p[1].x + f.p[2].x, f.p[0].y + f.p[1].y + f.p[2].y,
+                        f.p[0].z + f.p[1].z + f.p[2].z};
+    return a[axis];
+  };
+  const int mid = n / 2;
+  std::nth_element(fp.begin() + first, fp.begin() + first + mid, fp.begin() + first + n,
+                   [&](const FacePts &a, const FacePts &b) { return key(a) < key(b); });
+  const int l = build_subtree(sub, fp, first, mid);
+  const int r = build_subtree(sub, fp, first + mid, n - mid);
+  sub[me].left = l;
+  sub[me].right = r;
+  return me;
+}
 
 // bvh.cuh:113-121: bounds; leaf if n <= kMin; else sort by positions_[0].x and
 // split at mid = (n-1)/2.  The sort key never changes down the tree, so the
 // reference's per-node re-sort of an already sorted sub-range is the identity for
 // a stable sort; one stable sort of the whole range reproduces it.  (thrust::sort
 // does not promise an order for equal keys; this build fixes it as stable.)
-static int build_bvh_nodes(std::vector<BvhNode> &nodes, const std::vector<FacePts> &fp, int first, int n,
-                           int leaf_max, int face_base) {
+static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<BvhNode> &sub, std::vector<FacePts> &fp,
+                           int first, int n, int leaf_max, int face_base) {
   BvhNode nd;
   for (int k = 0; k < 3; k++) nd.mn[k] = INFINITY, nd.mx[k] = -INFINITY;
   for (int i = 0; i < n; i++)  // bvh.cuh:71-82
@@ -139,20 +194,22 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, const std::vector<FacePt
   int me = (int)nodes.size();
   nodes.push_back(nd);
   if (n <= leaf_max) {
-    nodes[me].left = face_base + first;
+    // faces of this leaf get their final physical order inside build_subtree
+    nodes[me].left = build_subtree(sub, fp, first, n);
     nodes[me].right = -n;
+    // sub-tree leaves index `faces` globally
     return me;
   }
   int mid = (n - 1) / 2;
-  int l = build_bvh_nodes(nodes, fp, first, mid + 1, leaf_max, face_base);
-  int r = build_bvh_nodes(nodes, fp, first + mid + 1, n - mid - 1, leaf_max, face_base);
+  int l = build_bvh_nodes(nodes, sub, fp, first, mid + 1, leaf_max, face_base);
+  int r = build_bvh_nodes(nodes, sub, fp, first + mid + 1, n - mid - 1, leaf_max, face_base);
   nodes[me].left = l;
   nodes[me].right = r;
   return me;
 }
 
 std::string Scene::flatten() {
-  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), faces.clear(),
+  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), subnodes.clear(), faces.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
   n_pgrams = n_triangles = n_spheres = 0;
@@ -260,21 +317,45 @@ std::string Scene::flatten() {
         if (hb.n > leaf_max)
           std::stable_sort(fp.begin(), fp.end(),
                            [](const FacePts &a, const FacePts &b) { return a.p[0].x < b.p[0].x; });
-        int face_base = (int)faces.size();
-        if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
-        for (int i = 0; i < hb.n; i++) {
-          TriRec t = make_tri(fp[i].p[0], fp[i].p[1], fp[i].p[2]);
-          FaceRec f;
-          for (int c = 0; c < 3; c++) f.p0[c] = t.p0[c], f.e1[c] = t.e1[c], f.e2[c] = t.e2[c], f.n[c] = t.n[c];
-          faces.push_back(f);
-          if (has_uv)
-            for (int j = 0; j < 6; j++) face_uv.push_back(fp[i].uv[j]);
-        }
+        for (int i = 0; i < hb.n; i++) fp[i].orig = i;  // index in the reference's face order
+        const int face_base = (int)faces.size();
+        const int sub_base = (int)subnodes.size();
         BvhRec br{};
+        std::vector<BvhNode> local_nodes, local_sub;
         // an empty mesh is a leaf that can never report a hit: it contributes nothing
-        br.root = hb.n > 0 ? build_bvh_nodes(nodes, fp, 0, hb.n, leaf_max, face_base) : -1;
+        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, local_sub, fp, 0, hb.n, leaf_max, face_base) : -1;
+        const int node_base = (int)nodes.size();
+        for (BvhNode nd : local_nodes) {  // rebase indices into the scene-wide arrays
+          if (nd.right < 0) {
+            nd.left += sub_base;
+          } else {
+            nd.left += node_base, nd.right += node_base;
+          }
+          nodes.push_back(nd);
+        }
+        for (BvhNode nd : local_sub) {
+          if (nd.right < 0) {
+            nd.left += face_base;
+          } else {
+            nd.left += sub_base, nd.right += sub_base;
+          }
+          subnodes.push_back(nd);
+        }
+        if (br.root >= 0) br.root += node_base;
+        if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
+        if (has_uv) face_uv.resize((size_t)(face_base + hb.n) * 6, 0.f);
+        for (int i = 0; i < hb.n; i++) {  // physical order = sub-tree order
+          TriRec t = make_tri(fp[i].p[0], fp[i].p[1], fp[i].p[2]);
+          FaceRec f{};
+          for (int c = 0; c < 3; c++) f.p0[c] = t.p0[c], f.e1[c] = t.e1[c], f.e2[c] = t.e2[c];
+          f.orig = fp[i].orig;
+          faces.push_back(f);
+          if (has_uv)  // texture coordinates stay in the reference's order, addressed by `orig`
+            for (int j = 0; j < 6; j++) face_uv[(size_t)(face_base + fp[i].orig) * 6 + j] = fp[i].uv[j];
+        }
         br.mat = hb.mat;
         br.has_uv = has_uv ? 1 : 0;
+        br.face_base = face_base;
         if (br.root >= 0) {
           bvh_recs.push_back(br);
           push_run(RUN_BVH, (int)bvh_recs.size() - 1);

@@ -71,25 +71,31 @@ struct TexRec {  // 32 B
   int64_t pad;
 };
 
+// Used for two trees.  (1) The reference's tree (bvh.cuh:113-121): exact bounds, median split of
+// the positions_[0].x-sorted faces, leaves of up to kMin faces; inner: left/right = child node
+// indices; leaf: left = root of the leaf's sub-tree in `subnodes`, right = -(face count).
+// (2) Per-leaf sub-trees (`subnodes`): conservative (padded) bounds over the leaf's faces;
+// inner: left/right = sub-node indices; leaf: left = first face, right = -(face count).
 struct BvhNode {  // 32 B
   float mn[3];
   float mx[3];
-  int32_t left;   // inner: index of left child; leaf: first face
-  int32_t right;  // inner: index of right child; leaf: -(face count)  (negative marks a leaf)
+  int32_t left;
+  int32_t right;  // negative marks a leaf
 };
 
 struct BvhRec {  // one per BVH hitable
   int32_t root;      // node index
   int32_t mat;       // -1: keep "material_ptr_ == nullptr"
   int32_t has_uv;
-  int32_t pad;
+  int32_t face_base;  // first face of this mesh: face_uv row = face_base + FaceRec::orig
 };
 
-struct FaceRec {  // 48 B, 16-byte aligned
+struct FaceRec {  // 48 B, 16-byte aligned; the unit normal is recomputed for the winner only
   float p0[3];
   float e1[3];
   float e2[3];
-  float n[3];
+  int32_t orig;  // index in the reference's (sorted) face order: decides ties, addresses face_uv
+  int32_t pad[2];
 };
 
 struct CameraDev {
@@ -106,6 +112,7 @@ struct SceneDev {
   const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
   const BvhRec *bvhs;
   const BvhNode *nodes;
+  const BvhNode *subnodes;
   const FaceRec *faces;
   const float *face_uv;  // 6 floats per face or nullptr
   const MatRec *mats;

@@ -23,7 +23,7 @@ def gather_to_root(t, dst=0):
     """Gather equal-sized tensors to ``dst``; returns the concatenation on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return t
     world = dist.get_world_size()
     if dist.get_rank() == dst:

@@ -215,7 +215,12 @@ class OracleBuilder:
         builder's ``state0``, which scene construction may have advanced (quirk g5)."""
         n = height * width
         if states is None:
-            states = rng_init(self.seed, n)
+            if pixel_ids is None:
+                states = rng_init(self.seed, n)
+            else:  # seed only the pixels that will be rendered (a full 4096^2 init takes minutes)
+                states = np.zeros((n, 6), dtype=np.uint32)
+                for idx in np.asarray(pixel_ids).reshape(-1):
+                    states[int(idx)] = rng_init(self.seed, 1, first=int(idx))[0]
             states[0] = self.state0
         rgb = np.zeros((n, 3), dtype=np.float32)
         rays = np.zeros(n, dtype=np.uint32)
