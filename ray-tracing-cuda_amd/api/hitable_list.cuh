@@ -1,16 +1,18 @@
 #pragma once
 #include "hitable.cuh"
 
-// HitableList: fixed array of up to 1024 entries, appended in order (hitable_list.cuh:10-21).
+// HitableList: the world.  Append order is kept all the way into the kernel because the
+// reference resolves equal-distance hits in favour of the earlier entry (hitable_list.cu:18).
+// Capacity 1024 as in hitable_list.cuh:10; the flatten kernel reads entries through at().
 class HitableList : public Hitable {
  public:
   constexpr static int kMaxHitables = 1024;
-  RT_API HitableList() : Hitable(rtapi::H_LIST) {}
-  RT_API void Append(Hitable *obj) { list_[list_len_++] = obj; }
-  RT_API int list_len() const { return list_len_; }
-  RT_API Hitable *at(int i) const { return list_[i]; }
+  RT_API HitableList() : Hitable(rtapi::H_LIST), count_(0) {}
+  RT_API void Append(Hitable *obj) { entries_[count_++] = obj; }
+  RT_API int list_len() const { return count_; }
+  RT_API Hitable *at(int i) const { return entries_[i]; }
 
  private:
-  Hitable *list_[kMaxHitables];
-  int list_len_ = 0;
+  int count_;
+  Hitable *entries_[kMaxHitables];
 };

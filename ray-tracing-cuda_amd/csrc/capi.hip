@@ -321,6 +321,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->tex_recs, &d.texs))) return rc;
   d.n_runs = (int)s->runs.size();
   d.n_mats = (int)s->mat_recs.size();
+  d.n_nodes = (int)s->nodes.size();
   d.cam = s->cam;
   s->dev = d;
   void *c = nullptr;

@@ -237,6 +237,28 @@ __device__ __forceinline__ V3 ball_sample(Rng &rng, float &sum) {
   return mk(x, y, z);
 }
 
+// Conservative "does the segment [lo, hi] of the ray come anywhere near this box" test, used
+// (a) on the padded sub-tree nodes and (b) as a cheap pre-reject in front of the reference's
+// exact AABB::Hit: if the ray never touches the box inflated by `pad`, no plane-crossing point
+// can lie on its surface.  Slack is applied on every comparison; NaNs cannot cause a cull.
+__device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V3 d, V3 inv_d, float lo, float hi) {
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv_d.x, inv_d.y, inv_d.z};
+  bool miss = false;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float mn = nd.mn[a] - pad, mx = nd.mx[a] + pad;
+    if (dd[a] == 0.f) {
+      miss = miss || (oo[a] < mn) || (oo[a] > mx);
+    } else {
+      float t0 = (mn - oo[a]) * ii[a], t1 = (mx - oo[a]) * ii[a];
+      float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+      lo = fmaxf(lo, tn - fabsf(tn) * 1e-5f);
+      hi = fminf(hi, tf + fabsf(tf) * 1e-5f);
+    }
+  }
+  return !(miss || lo > hi);
+}
+
 struct Hit {
   bool ok;
   float t;        // float(record.t)
@@ -250,7 +272,7 @@ struct Hit {
 // Parallelepiped list is equivalent to its six parallelograms inlined at its
 // position (DESIGN.md "List flattening").
 template <uint32_t F>
-__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, V3 o, V3 d) {
   constexpr bool DT = (F & F_SPHERE) != 0;
   typedef typename TSel<DT>::type T;
   bool ok = false;
@@ -375,8 +397,17 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
         float fu = 0.f, fv = 0.f;
         while (top > 0) {
           int ni = stack[--top];
-          const BvhNode nd = sc.nodes[ni];
-          if (!first && !aabb_test<T>(nd, o, d, bt_to)) continue;
+          const BvhNode nd = ni < lds_nodes ? s_nodes[ni] : sc.nodes[ni];
+          if (!first) {
+            // cheap conservative reject, then the reference's exact surface-crossing test
+            float ext = fmaxf(fmaxf(nd.mx[0] - nd.mn[0], nd.mx[1] - nd.mn[1]), nd.mx[2] - nd.mn[2]);
+            float mag = fmaxf(fmaxf(fmaxf(fabsf(nd.mn[0]), fabsf(nd.mx[0])), fmaxf(fabsf(nd.mn[1]), fabsf(nd.mx[1]))),
+                              fmaxf(fabsf(nd.mn[2]), fabsf(nd.mx[2])));
+            if (!slab_touch(nd, 1e-4f * ext + 1e-5f * mag + 1e-30f, o, d, inv_d, T_FROM_F * 0.999f,
+                            (float)bt_to * 1.0001f + 1e-6f))
+              continue;
+            if (!aabb_test<T>(nd, o, d, bt_to)) continue;
+          }
           first = false;
           if (nd.right >= 0) {
             stack[top++] = nd.right;
@@ -396,22 +427,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, V3 o, V3 d) {
           sstack[stop++] = nd.left;
           while (stop > 0) {
             const BvhNode sn = sc.subnodes[sstack[--stop]];
-            // slab test with slack on both ends; NaNs (0 * inf) make a compare false -> visit
-            float lo = T_FROM_F * 0.999f, hi = (float)best * 1.0001f + 1e-6f;
-            const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv_d.x, inv_d.y, inv_d.z};
-            bool miss = false;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-              if (dd[a] == 0.f) {
-                miss = miss || (oo[a] < sn.mn[a]) || (oo[a] > sn.mx[a]);
-              } else {
-                float t0 = (sn.mn[a] - oo[a]) * ii[a], t1 = (sn.mx[a] - oo[a]) * ii[a];
-                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-                lo = fmaxf(lo, tn - fabsf(tn) * 1e-5f);
-                hi = fminf(hi, tf + fabsf(tf) * 1e-5f);
-              }
-            }
-            if (miss || lo > hi) continue;
+            if (!slab_touch(sn, 0.f, o, d, inv_d, T_FROM_F * 0.999f, (float)best * 1.0001f + 1e-6f)) continue;
             if (sn.right >= 0) {
               sstack[stop++] = sn.right;
               sstack[stop++] = sn.left;
@@ -469,7 +485,9 @@ struct LaunchCfg {
   int32_t lds_mats;    // materials staged in LDS (0: read them from global memory)
   int32_t wide_ids;    // 1: uint16 stack entries
   int32_t stack_off;   // byte offset of the id stack inside dynamic LDS
-  int32_t pad;
+  int32_t nodes_off;   // byte offset of the staged reference-tree nodes
+  int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
+  int32_t pad[3];
 };
 
 template <uint32_t F>
@@ -481,11 +499,17 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
   MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
   uint8_t *stack8 = smem + lc.stack_off;
   uint16_t *stack16 = reinterpret_cast<uint16_t *>(smem + lc.stack_off);
+  const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
   const bool mats_in_lds = lc.lds_mats > 0;
   if (mats_in_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_mats);
     for (int w = threadIdx.x; w < lc.lds_mats * 8; w += blockDim.x) dst[w] = src[w];
+  }
+  if ((F & F_BVH) && lc.lds_nodes > 0) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.nodes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.nodes_off);
+    for (int w = threadIdx.x; w < lc.lds_nodes * 8; w += blockDim.x) dst[w] = src[w];
   }
   __syncthreads();
 
@@ -593,7 +617,7 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
     if (!__any(active)) break;
 
     if (active) {
-      Hit h = closest_hit<F>(sc, o, d);
+      Hit h = closest_hit<F>(sc, s_nodes, (F & F_BVH) ? lc.lds_nodes : 0, o, d);
       rays++;
 
       V3 result = splat(0.f);
@@ -786,7 +810,10 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
   lc.stack_off = (int32_t)off;
   size_t stack = (variant & F_TEX) ? 0 : (size_t)(fr.max_depth > 0 ? fr.max_depth : 1) * threads * (lc.wide_ids ? 2 : 1);
-  *lds_bytes = off + stack;
+  size_t noff = (off + stack + 15) & ~(size_t)15;
+  lc.nodes_off = (int32_t)noff;
+  lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
+  *lds_bytes = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
   return lc;
 }
 

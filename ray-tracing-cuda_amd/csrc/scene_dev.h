@@ -104,7 +104,8 @@ struct CameraDev {
   int32_t defocus;
 };
 
-constexpr int kLdsMats = 512;  // at most this many material records are staged in LDS
+constexpr int kLdsMats = 512;   // at most this many material records are staged in LDS
+constexpr int kLdsNodes = 512;  // ... and this many reference-tree nodes (16 KiB)
 
 struct SceneDev {
   const Run *runs;
@@ -117,7 +118,7 @@ struct SceneDev {
   const float *face_uv;  // 6 floats per face or nullptr
   const MatRec *mats;
   const TexRec *texs;
-  int32_t n_runs, n_mats;
+  int32_t n_runs, n_mats, n_nodes, pad0;
   CameraDev cam;
 };
 

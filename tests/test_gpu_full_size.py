@@ -18,12 +18,12 @@ def _oracle_pixels(name, h, w, spp, depth, ids, **kw):
 
 
 def test_c2_cornell_1024sq_1024spp_depth50_sampled_pixels():
-    """configs[1] at full size: 96 random pixels (plus the corners) bit-exact vs the oracle."""
+    """configs[1] at full size: 512 random pixels (plus the corners) bit-exact vs the oracle."""
     h = w = 1024
     spp, depth = 1024, 50
     g_rgb, g_rays, _, g_total, _ = common.gpu_render("cornell_box", h, w, spp, depth)
     rng = np.random.default_rng(2026)
-    ids = np.unique(np.concatenate([rng.integers(0, h * w, 96), [0, w - 1, (h - 1) * w, h * w - 1]])).astype(np.int32)
+    ids = np.unique(np.concatenate([rng.integers(0, h * w, 512), [0, w - 1, (h - 1) * w, h * w - 1]])).astype(np.int32)
     o_rgb, o_rays = _oracle_pixels("cornell_box", h, w, spp, depth, ids)
     assert np.array_equal(g_rays.reshape(-1)[ids], o_rays)
     assert np.array_equal(g_rgb.reshape(-1, 3)[ids], o_rgb)
@@ -44,10 +44,10 @@ def test_c2_shape_shard_invariance_and_determinism():
 
 def test_c3_bunny_mesh_1024sq_sampled_pixels():
     """configs[2] shape (procedural stand-in mesh, 70,272 faces, reference leaf size 2048) at
-    1024x1024 with reduced spp; sampled pixels bit-exact vs the oracle."""
+    1024x1024 with reduced spp (16 of 512); sampled pixels bit-exact vs the oracle."""
     from rtmi import scenes
     h = w = 1024
-    spp, depth = 2, 10
+    spp, depth = 16, 10
     faces = scenes.procedural_bunny_mesh()
     g_rgb, g_rays, _, g_total, _ = common.gpu_render("bunny", h, w, spp, depth, faces=faces)
     rng = np.random.default_rng(7)
