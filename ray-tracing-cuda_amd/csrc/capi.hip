@@ -56,6 +56,7 @@ static bool make_frame(const rtmi_frame *f, FrameDev *out) {
 // jump matrices, uploaded once per device
 static std::mutex g_mu;
 static std::unordered_map<int, uint32_t *> g_jump;
+static std::unordered_map<int, int> g_cus;
 static int device_jump(uint32_t **out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -448,14 +449,23 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev != s->device) return fail(RTMI_ERR_INVALID, "scene was committed on another device");
-  hipDeviceProp_t prop;
-  HIP_TRY(hipGetDeviceProperties(&prop, dev));
+  int n_cu = 0;
+  {  // compute-unit count, cached per device (hipGetDeviceProperties is slow)
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_cus.find(dev);
+    if (it == g_cus.end()) {
+      hipDeviceProp_t prop;
+      HIP_TRY(hipGetDeviceProperties(&prop, dev));
+      it = g_cus.emplace(dev, prop.multiProcessorCount).first;
+    }
+    n_cu = it->second;
+  }
   const int threads = g_threads > 0 ? g_threads : 256;
   const uint32_t variant = pick_variant(s->features);
   int per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : render_occupancy(variant, s->dev, d, threads);
   if (per_cu <= 0) per_cu = 1;
   int64_t want = (d.items + threads - 1) / threads;
-  int64_t cap = (int64_t)prop.multiProcessorCount * per_cu;
+  int64_t cap = (int64_t)n_cu * per_cu;
   int blocks = (int)(want < cap ? want : cap);
   if (blocks < 1) blocks = 1;
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream));
