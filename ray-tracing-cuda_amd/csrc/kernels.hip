@@ -259,6 +259,8 @@ __device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V
   return !(miss || lo > hi);
 }
 
+constexpr int kSubStack = 24;  // sub-tree stack entries per lane (LDS)
+
 struct Hit {
   bool ok;
   float t;        // float(record.t)
@@ -272,7 +274,8 @@ struct Hit {
 // Parallelepiped list is equivalent to its six parallelograms inlined at its
 // position (DESIGN.md "List flattening").
 template <uint32_t F>
-__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, V3 o, V3 d) {
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes,
+                                           int *s_substack, V3 o, V3 d) {
   constexpr bool DT = (F & F_SPHERE) != 0;
   typedef typename TSel<DT>::type T;
   bool ok = false;
@@ -422,30 +425,44 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           bool have = false;
           int best_face = 0, best_orig = -1;
           float lu = 0.f, lv = 0.f;
-          int sstack[32];
+          // sub-tree stack in LDS, [level][thread] (a register array indexed per lane turns
+          // into select chains); depth <= log2(2048/4)+2, kSubStack entries are ample
+          const int sst = blockDim.x;
+          int *sstack = s_substack + threadIdx.x;
           int stop = 0;
-          sstack[stop++] = nd.left;
+          sstack[(stop++) * sst] = nd.left;
           while (stop > 0) {
-            const BvhNode sn = sc.subnodes[sstack[--stop]];
+            const BvhNode sn = sc.subnodes[sstack[(--stop) * sst]];
             if (!slab_touch(sn, 0.f, o, d, inv_d, T_FROM_F * 0.999f, (float)best * 1.0001f + 1e-6f)) continue;
             if (sn.right >= 0) {
-              sstack[stop++] = sn.right;
-              sstack[stop++] = sn.left;
+              if (stop + 2 <= kSubStack) {  // cannot trigger for trees built by scene.hip; keeps LDS safe
+                sstack[(stop++) * sst] = sn.right;
+                sstack[(stop++) * sst] = sn.left;
+              }
               continue;
             }
+            // A sub-leaf holds at most 4 faces.  All their records (3 x 16 B each) are fetched
+            // before any test so the memory round trips overlap; the faces array carries 4
+            // records of padding, so the fixed-count fetch never leaves the allocation.
             const int cnt = -sn.right;
-            for (int fi = 0; fi < cnt; fi++) {
-              const FaceRec &fc = sc.faces[sn.left + fi];
-              float t = 0.f, u = 0.f, v = 0.f;
-              if (tri_test<T>(mk(fc.p0[0], fc.p0[1], fc.p0[2]), mk(fc.e1[0], fc.e1[1], fc.e1[2]),
-                              mk(fc.e2[0], fc.e2[1], fc.e2[2]), o, d, best, t, u, v)) {
-                const int orig = fc.orig;
-                if ((T)t < best || !have || orig > best_orig) {  // t <= best holds here
-                  best = (T)t;
-                  have = true;
-                  best_face = sn.left + fi;
-                  best_orig = orig;
-                  lu = u, lv = v;
+            const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + sn.left);
+            float4 q[12];
+#pragma unroll
+            for (int w = 0; w < 12; w++) q[w] = fp4[w];
+#pragma unroll
+            for (int fi = 0; fi < 4; fi++) {
+              if (fi < cnt) {
+                const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
+                float t = 0.f, u = 0.f, v = 0.f;
+                if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, best, t, u, v)) {
+                  const int orig = __float_as_int(c.y);
+                  if ((T)t < best || !have || orig > best_orig) {  // t <= best holds here
+                    best = (T)t;
+                    have = true;
+                    best_face = sn.left + fi;
+                    best_orig = orig;
+                    lu = u, lv = v;
+                  }
                 }
               }
             }
@@ -487,7 +504,8 @@ struct LaunchCfg {
   int32_t stack_off;   // byte offset of the id stack inside dynamic LDS
   int32_t nodes_off;   // byte offset of the staged reference-tree nodes
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
-  int32_t pad[3];
+  int32_t substack_off;  // byte offset of the per-lane sub-tree stacks (BVH variants)
+  int32_t pad[2];
 };
 
 template <uint32_t F>
@@ -617,7 +635,8 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
     if (!__any(active)) break;
 
     if (active) {
-      Hit h = closest_hit<F>(sc, s_nodes, (F & F_BVH) ? lc.lds_nodes : 0, o, d);
+      Hit h = closest_hit<F>(sc, s_nodes, (F & F_BVH) ? lc.lds_nodes : 0,
+                             reinterpret_cast<int *>(smem + lc.substack_off), o, d);
       rays++;
 
       V3 result = splat(0.f);
@@ -813,7 +832,9 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t noff = (off + stack + 15) & ~(size_t)15;
   lc.nodes_off = (int32_t)noff;
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
-  *lds_bytes = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
+  size_t soff = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
+  lc.substack_off = (int32_t)soff;
+  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)kSubStack * threads * sizeof(int) : 0);
   return lc;
 }
 

@@ -366,6 +366,8 @@ std::string Scene::flatten() {
     }
   }
   if (!face_uv.empty()) face_uv.resize(faces.size() * 6, 0.f);
+  if (!faces.empty())  // the kernel fetches sub-leaf faces four at a time
+    for (int i = 0; i < 4; i++) faces.push_back(FaceRec{});
   if (!tris.empty()) {  // prefetch target past the last pair (fetched, never tested)
     tris.push_back(HotTri{});
     tris.push_back(HotTri{});

@@ -90,7 +90,7 @@ struct BvhRec {  // one per BVH hitable
   int32_t face_base;  // first face of this mesh: face_uv row = face_base + FaceRec::orig
 };
 
-struct FaceRec {  // 48 B, 16-byte aligned; the unit normal is recomputed for the winner only
+struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the winner only
   float p0[3];
   float e1[3];
   float e2[3];

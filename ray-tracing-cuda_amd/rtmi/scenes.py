@@ -125,46 +125,40 @@ def bunny(b, aspect, faces, k_min=2048):
     b.bvh(faces, white, k_min=k_min)
 
 
-def procedural_bunny_mesh(n_u=192, n_v=184, seed=7):
-    """Deterministic stand-in for the absent Stanford bunny: a bumpy closed blob of
-    2*n_u*(n_v-1) triangles (default 70,272; the Stanford mesh has 69,451) filling the
-    bunny's bounding box [-0.095,0.061]x[0.033,0.187]x[-0.062,0.059] so the camera of
-    scenes/bunny.cu:47 frames it.  Pure float32 table arithmetic on integer grids; no
-    RNG library (a fixed LCG) so it is reproducible anywhere."""
+def procedural_bunny_mesh(n=76, seed=7):
+    """Deterministic stand-in for the absent Stanford bunny: a bumpy closed blob of 12*n*n
+    triangles (default 69,312; the Stanford mesh has 69,451) filling the bunny's bounding box
+    [-0.095,0.061]x[0.033,0.187]x[-0.062,0.059] so the camera of scenes/bunny.cu:47 frames it.
+    Cube-sphere tessellation (six n x n grids pushed onto the unit sphere): no polar triangle
+    fans, all faces of similar size, like a scanned mesh.  float64 table arithmetic narrowed
+    once to float32; a fixed LCG instead of an RNG library, so it is reproducible anywhere."""
     cx, cy, cz = -0.017, 0.110, -0.0015
-    rx, ry, rz = 0.078, 0.077, 0.0605
+    rx, ry, rz = 0.070, 0.069, 0.054
     state = seed & 0xFFFFFFFF
-    bumps = []
-    for _ in range(12):
+    waves = []
+    for _ in range(10):
         vals = []
-        for _ in range(4):
+        for _ in range(7):
             state = (1664525 * state + 1013904223) & 0xFFFFFFFF
             vals.append(state / 4294967296.0)
-        bumps.append(vals)
-    us = (np.arange(n_u, dtype=np.float64) / n_u) * 2.0 * math.pi
-    vs = (np.arange(1, n_v, dtype=np.float64) / n_v) * math.pi
-    U, V = np.meshgrid(us, vs, indexing="xy")  # (n_v-1, n_u)
-    rad = np.ones_like(U)
-    for (a, bb, c, d) in bumps:
-        rad += 0.035 * np.sin((1 + int(a * 5)) * U + 6.28 * bb) * np.sin((1 + int(c * 4)) * V + 6.28 * d)
-    X = cx + rx * rad * np.sin(V) * np.cos(U)
-    Y = cy - ry * rad * np.cos(V)
-    Z = cz + rz * rad * np.sin(V) * np.sin(U)
-    ring = np.stack([X, Y, Z], axis=-1).astype(np.float32)  # (n_v-1, n_u, 3)
-    south = np.array([cx, cy - ry, cz], dtype=np.float32)
-    north = np.array([cx, cy + ry, cz], dtype=np.float32)
+        waves.append(vals)
+    g = (np.arange(n + 1, dtype=np.float64) / n) * 2.0 - 1.0
+    A, B = np.meshgrid(g, g, indexing="ij")  # (n+1, n+1)
+    one = np.ones_like(A)
+    cube_faces = [(one, A, B), (-one, B, A), (B, one, A), (A, -one, B), (A, B, one), (B, A, -one)]
     tris = []
-    nxt = np.roll(np.arange(n_u), -1)
-    # caps
-    r0, r1 = ring[0], ring[-1]
-    tris.append(np.stack([np.broadcast_to(south, r0.shape), r0[nxt], r0], axis=1))
-    tris.append(np.stack([np.broadcast_to(north, r1.shape), r1, r1[nxt]], axis=1))
-    for k in range(n_v - 2):
-        a, bq = ring[k], ring[k + 1]
-        tris.append(np.stack([a, a[nxt], bq], axis=1))
-        tris.append(np.stack([a[nxt], bq[nxt], bq], axis=1))
-    faces = np.concatenate(tris, axis=0).astype(np.float32)
-    return np.ascontiguousarray(faces)
+    for (X, Y, Z) in cube_faces:
+        L = np.sqrt(X * X + Y * Y + Z * Z)
+        dx, dy, dz = X / L, Y / L, Z / L
+        rad = np.ones_like(dx)
+        for (a, bb, c, d, e, f, h) in waves:
+            k = 1.0 + np.floor(a * 4.0)
+            rad += 0.03 * np.sin(k * (3.0 * bb * dx + 3.0 * c * dy + 3.0 * d * dz) + 6.28 * e) * (0.5 + 0.5 * f) * (0.6 + 0.4 * h)
+        P = np.stack([cx + rx * rad * dx, cy + ry * rad * dy, cz + rz * rad * dz], axis=-1).astype(np.float32)
+        p00, p10, p01, p11 = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+        tris.append(np.stack([p00, p10, p11], axis=2).reshape(-1, 3, 3))
+        tris.append(np.stack([p00, p11, p01], axis=2).reshape(-1, 3, 3))
+    return np.ascontiguousarray(np.concatenate(tris, axis=0).astype(np.float32))
 
 
 # --------------------------------------------------------------------------- birthday

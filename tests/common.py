@@ -6,11 +6,10 @@ from rtmi import scenes
 _MESH = {}
 
 
-def small_mesh(n_u=24, n_v=20):
-    key = (n_u, n_v)
-    if key not in _MESH:
-        _MESH[key] = scenes.procedural_bunny_mesh(n_u, n_v)
-    return _MESH[key]
+def small_mesh(n=9):
+    if n not in _MESH:
+        _MESH[n] = scenes.procedural_bunny_mesh(n)  # 12*n*n triangles (972 by default)
+    return _MESH[n]
 
 
 def build_scene(b, name, aspect=1.0, **kw):

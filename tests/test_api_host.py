@@ -112,7 +112,7 @@ def test_make_assets_obj_round_trips_every_float(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import make_assets
     scenes = make_assets.load_scenes()
-    faces = scenes.procedural_bunny_mesh(12, 10)
+    faces = scenes.procedural_bunny_mesh(5)
     p = tmp_path / "m.obj"
     make_assets.write_obj(str(p), faces)
     verts, tris = [], []

@@ -43,7 +43,7 @@ def test_c2_shape_shard_invariance_and_determinism():
 
 
 def test_c3_bunny_mesh_1024sq_sampled_pixels():
-    """configs[2] shape (procedural stand-in mesh, 70,272 faces, reference leaf size 2048) at
+    """configs[2] shape (procedural stand-in mesh, 69,312 faces, reference leaf size 2048) at
     1024x1024 with reduced spp (16 of 512); sampled pixels bit-exact vs the oracle."""
     from rtmi import scenes
     h = w = 1024

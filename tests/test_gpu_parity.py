@@ -169,7 +169,7 @@ def test_bvh_with_texture_coordinates_and_inner_nodes():
     import torch
     from rtmi import scenes
     from rtmi.scenes import v3, PI_D
-    faces = scenes.procedural_bunny_mesh(20, 16)
+    faces = scenes.procedural_bunny_mesh(8)
     rng = np.random.default_rng(5)
     uvs = rng.uniform(0, 1, size=(faces.shape[0], 6)).astype(np.float32)
     tex = scenes.procedural_earthmap(32, 64)

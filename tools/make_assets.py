@@ -2,7 +2,7 @@
 """Writes stand-ins for the two assets the reference does not ship (its .gitignore excludes
 resources/): resources/bunny.obj (scenes/bunny.cu:102) and resources/earthmap.jpg
 (scenes/birthday.cu:80).  Both are procedural and deterministic (rtmi/scenes.py):
-a 70,272-triangle closed blob filling the Stanford bunny's bounding box, and an
+a 69,312-triangle closed blob filling the Stanford bunny's bounding box, and an
 equirectangular colour map saved as a baseline JPEG.
 
 usage: tools/make_assets.py [out_dir]   (default: current directory)
