@@ -11,6 +11,12 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no native artefacts (they are git-ignored): build what is missing
+    lib = os.path.join(ROOT, "ray-tracing-cuda_amd", "lib", "librtmi.so")
+    orc = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
