@@ -259,8 +259,6 @@ __device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V
   return !(miss || lo > hi);
 }
 
-constexpr int kSubStack = 24;  // sub-tree stack entries per lane (LDS)
-
 struct Hit {
   bool ok;
   float t;        // float(record.t)
@@ -390,17 +388,24 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         // then the right child's box is tested against the t_to the left subtree
         // left behind; any accepted face (t <= t_to, inclusive) replaces the record.
         // The root's own box is never tested (bvh.cuh:175-177).
-        int stack[40];
+        // reference-tree stack: LDS, [level][thread], above the sub-tree stack's kSubStack levels
+        int *stack = s_substack + (size_t)kSubStack * blockDim.x + threadIdx.x;
+        const int rst = blockDim.x;
         int top = 0;
-        stack[top++] = br.root;
+        stack[(top++) * rst] = br.root;
         bool first = true;
         T bt_to = t_to;
         bool bhit = false;
         int bface = 0;
         float fu = 0.f, fv = 0.f;
         while (top > 0) {
-          int ni = stack[--top];
-          const BvhNode nd = ni < lds_nodes ? s_nodes[ni] : sc.nodes[ni];
+          int ni = stack[(--top) * rst];
+          BvhNode nd;
+          if (ni < lds_nodes) {
+            nd = s_nodes[ni];
+          } else {
+            nd = sc.nodes[ni];
+          }
           if (!first) {
             // cheap conservative reject, then the reference's exact surface-crossing test
             float ext = fmaxf(fmaxf(nd.mx[0] - nd.mn[0], nd.mx[1] - nd.mn[1]), nd.mx[2] - nd.mn[2]);
@@ -413,8 +418,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           }
           first = false;
           if (nd.right >= 0) {
-            stack[top++] = nd.right;
-            stack[top++] = nd.left;
+            stack[(top++) * rst] = nd.right;
+            stack[(top++) * rst] = nd.left;
             continue;
           }
           // ---- leaf query (bvh.cuh:125-136): among this leaf's faces accepted with
@@ -426,42 +431,54 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           int best_face = 0, best_orig = -1;
           float lu = 0.f, lv = 0.f;
           // sub-tree stack in LDS, [level][thread] (a register array indexed per lane turns
-          // into select chains); depth <= log2(2048/4)+2, kSubStack entries are ample
+          // into select chains); entries >= 0 are 4-wide nodes, < 0 encoded face ranges
           const int sst = blockDim.x;
           int *sstack = s_substack + threadIdx.x;
           int stop = 0;
           sstack[(stop++) * sst] = nd.left;
           while (stop > 0) {
-            const BvhNode sn = sc.subnodes[sstack[(--stop) * sst]];
-            if (!slab_touch(sn, 0.f, o, d, inv_d, T_FROM_F * 0.999f, (float)best * 1.0001f + 1e-6f)) continue;
-            if (sn.right >= 0) {
-              if (stop + 2 <= kSubStack) {  // cannot trigger for trees built by scene.hip; keeps LDS safe
-                sstack[(stop++) * sst] = sn.right;
-                sstack[(stop++) * sst] = sn.left;
+            const int e = sstack[(--stop) * sst];
+            if (e >= 0) {
+              // one 128-byte node: four padded child boxes (plane-major) + four child references
+              const float4 *np4 = reinterpret_cast<const float4 *>(sc.subnodes + e);
+              const float4 mnx = np4[0], mny = np4[1], mnz = np4[2], mxx = np4[3], mxy = np4[4], mxz = np4[5];
+              const float4 chf = np4[6];
+              const float lo0 = T_FROM_F * 0.999f, hi0 = (float)best * 1.0001f + 1e-6f;
+              const float cmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, cmny[4] = {mny.x, mny.y, mny.z, mny.w},
+                          cmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, cmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w},
+                          cmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, cmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+              const int cch[4] = {__float_as_int(chf.x), __float_as_int(chf.y), __float_as_int(chf.z),
+                                  __float_as_int(chf.w)};
+#pragma unroll
+              for (int c = 0; c < 4; c++) {
+                BvhNode bx;
+                bx.mn[0] = cmnx[c], bx.mn[1] = cmny[c], bx.mn[2] = cmnz[c];
+                bx.mx[0] = cmxx[c], bx.mx[1] = cmxy[c], bx.mx[2] = cmxz[c];
+                // an unused slot has mn = +inf, mx = -inf and fails the test
+                if (cch[c] != -1 && slab_touch(bx, 0.f, o, d, inv_d, lo0, hi0)) sstack[(stop++) * sst] = cch[c];
               }
-              continue;
-            }
-            // A sub-leaf holds at most 4 faces.  All their records (3 x 16 B each) are fetched
-            // before any test so the memory round trips overlap; the faces array carries 4
-            // records of padding, so the fixed-count fetch never leaves the allocation.
-            const int cnt = -sn.right;
-            const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + sn.left);
-            float4 q[12];
+            } else {
+              // <= 4 faces: all records (3 x 16 B each) are fetched before any test so the
+              // memory round trips overlap; `faces` carries 4 records of padding
+              const int enc = -(e + 1), cnt = enc & 7, first = enc >> 3;
+              const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + first);
+              float4 q[12];
 #pragma unroll
-            for (int w = 0; w < 12; w++) q[w] = fp4[w];
+              for (int w = 0; w < 12; w++) q[w] = fp4[w];
 #pragma unroll
-            for (int fi = 0; fi < 4; fi++) {
-              if (fi < cnt) {
-                const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
-                float t = 0.f, u = 0.f, v = 0.f;
-                if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, best, t, u, v)) {
-                  const int orig = __float_as_int(c.y);
-                  if ((T)t < best || !have || orig > best_orig) {  // t <= best holds here
-                    best = (T)t;
-                    have = true;
-                    best_face = sn.left + fi;
-                    best_orig = orig;
-                    lu = u, lv = v;
+              for (int fi = 0; fi < 4; fi++) {
+                if (fi < cnt) {
+                  const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
+                  float t = 0.f, u = 0.f, v = 0.f;
+                  if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, best, t, u, v)) {
+                    const int orig = __float_as_int(c.y);
+                    if ((T)t < best || !have || orig > best_orig) {  // t <= best holds here
+                      best = (T)t;
+                      have = true;
+                      best_face = first + fi;
+                      best_orig = orig;
+                      lu = u, lv = v;
+                    }
                   }
                 }
               }
@@ -834,7 +851,7 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
   size_t soff = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
   lc.substack_off = (int32_t)soff;
-  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)kSubStack * threads * sizeof(int) : 0);
+  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)(kSubStack + kRefStack) * threads * sizeof(int) : 0);
   return lc;
 }
 

@@ -63,7 +63,8 @@ struct Scene {
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;
   std::vector<BvhNode> nodes;
-  std::vector<BvhNode> subnodes;
+  std::vector<SubNode4> subnodes;
+  int sub_depth = 0;  // deepest sub-tree (levels of SubNode4)
   std::vector<FaceRec> faces;
   std::vector<float> face_uv;
   std::vector<MatRec> mat_recs;

@@ -119,57 +119,96 @@ struct FacePts {
   int orig;
 };
 
-// Sub-tree over the faces [first, first+n) of one reference leaf.  Faces are reordered inside
-// the range (each keeps `orig`); bounds are padded so that no face the binary32 Moller-Trumbore
-// test can accept is ever culled by the (also slack) slab test of the kernel.  The answer of a
-// leaf query does not depend on visiting order: it is the accepted face with the smallest t, the
-// highest reference index among equal t (bvh.cuh:127-134 scans in order with `t <= t_to`).
-static int build_subtree(std::vector<BvhNode> &sub, std::vector<FacePts> &fp, int first, int n) {
-  BvhNode nd;
-  float cmn[3], cmx[3];
-  for (int k = 0; k < 3; k++) nd.mn[k] = cmn[k] = INFINITY, nd.mx[k] = cmx[k] = -INFINITY;
-  for (int i = 0; i < n; i++) {
-    float c[3] = {0, 0, 0};
+// Padded bounds of faces [first, first+n): no face the binary32 Moller-Trumbore test can accept
+// is ever culled by the (also slack) slab test of the kernel.
+static void padded_bounds(const std::vector<FacePts> &fp, int first, int n, float mn[3], float mx[3]) {
+  for (int k = 0; k < 3; k++) mn[k] = INFINITY, mx[k] = -INFINITY;
+  for (int i = 0; i < n; i++)
     for (int j = 0; j < 3; j++) {
       const V3 &p = fp[first + i].p[j];
       const float q[3] = {p.x, p.y, p.z};
-      for (int k = 0; k < 3; k++) {
-        nd.mn[k] = fminf(nd.mn[k], q[k]);
-        nd.mx[k] = fmaxf(nd.mx[k], q[k]);
-        c[k] += q[k];
-      }
+      for (int k = 0; k < 3; k++) mn[k] = fminf(mn[k], q[k]), mx[k] = fmaxf(mx[k], q[k]);
     }
-    for (int k = 0; k < 3; k++) cmn[k] = fminf(cmn[k], c[k]), cmx[k] = fmaxf(cmx[k], c[k]);
-  }
   float diag = 0.f, mag = 0.f;
   for (int k = 0; k < 3; k++) {
-    diag = fmaxf(diag, nd.mx[k] - nd.mn[k]);
-    mag = fmaxf(mag, fmaxf(fabsf(nd.mn[k]), fabsf(nd.mx[k])));
+    diag = fmaxf(diag, mx[k] - mn[k]);
+    mag = fmaxf(mag, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
   }
   const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
-  for (int k = 0; k < 3; k++) nd.mn[k] -= pad, nd.mx[k] += pad;
-  const int me = (int)sub.size();
-  sub.push_back(nd);
-  if (n <= 4) {
-    sub[me].left = first;
-    sub[me].right = -n;
-    return me;
+  for (int k = 0; k < 3; k++) mn[k] -= pad, mx[k] += pad;
+}
+
+// Median split of [first, first+n) along the longest axis of the centroid bounds; returns the
+// size of the first part.
+static int split_range(std::vector<FacePts> &fp, int first, int n) {
+  float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  auto centroid3 = [](const FacePts &f, float c[3]) {
+    c[0] = f.p[0].x + f.p[1].x + f.p[2].x, c[1] = f.p[0].y + f.p[1].y + f.p[2].y, c[2] = f.p[0].z + f.p[1].z + f.p[2].z;
+  };
+  for (int i = 0; i < n; i++) {
+    float c[3];
+    centroid3(fp[first + i], c);
+    for (int k = 0; k < 3; k++) cmn[k] = fminf(cmn[k], c[k]), cmx[k] = fmaxf(cmx[k], c[k]);
   }
   int axis = 0;
   for (int k = 1; k < 3; k++)
     if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-  auto key = [axis](const FacePts &f) {
-    const float a[3] = {f.p[0].x + f.p[1].x + f.p[2].x, f.p[0].y + f.p[1].y + f.p[2].y,
-                        f.p[0].z + f.p[1].z + f.p[2].z};
-    return a[axis];
-  };
   const int mid = n / 2;
   std::nth_element(fp.begin() + first, fp.begin() + first + mid, fp.begin() + first + n,
-                   [&](const FacePts &a, const FacePts &b) { return key(a) < key(b); });
-  const int l = build_subtree(sub, fp, first, mid);
-  const int r = build_subtree(sub, fp, first + mid, n - mid);
-  sub[me].left = l;
-  sub[me].right = r;
+                   [&](const FacePts &a, const FacePts &b) {
+                     float ca[3], cb[3];
+                     centroid3(a, ca), centroid3(b, cb);
+                     return ca[axis] < cb[axis];
+                   });
+  return mid;
+}
+
+// 4-wide sub-tree over the faces [first, first+n) of one reference leaf.  Faces are reordered
+// inside the range (each keeps `orig`).  The answer of a leaf query does not depend on visiting
+// order: it is the accepted face with the smallest t, the highest reference index among equal t
+// (bvh.cuh:127-134 scans in order with `t <= t_to`).  Returns the node index; *depth = levels.
+static int build_subtree(std::vector<SubNode4> &sub, std::vector<FacePts> &fp, int first, int n, int *depth) {
+  const int me = (int)sub.size();
+  sub.emplace_back();
+  int parts[4][2];
+  int np = 0;
+  if (n <= 4) {
+    parts[np][0] = first, parts[np][1] = n, np++;
+  } else {
+    const int m = split_range(fp, first, n);
+    const int halves[2][2] = {{first, m}, {first + m, n - m}};
+    for (int h = 0; h < 2; h++) {
+      if (halves[h][1] <= 4) {
+        parts[np][0] = halves[h][0], parts[np][1] = halves[h][1], np++;
+      } else {
+        const int q = split_range(fp, halves[h][0], halves[h][1]);
+        parts[np][0] = halves[h][0], parts[np][1] = q, np++;
+        parts[np][0] = halves[h][0] + q, parts[np][1] = halves[h][1] - q, np++;
+      }
+    }
+  }
+  SubNode4 nd;
+  int deepest = 0;
+  for (int c = 0; c < 4; c++) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int child = -1;  // count 0: never visited (empty box)
+    if (c < np) {
+      padded_bounds(fp, parts[c][0], parts[c][1], mn, mx);
+      if (parts[c][1] <= 4) {
+        child = -(parts[c][0] * 8 + parts[c][1]) - 1;
+      } else {
+        int d = 0;
+        child = build_subtree(sub, fp, parts[c][0], parts[c][1], &d);
+        deepest = std::max(deepest, d);
+      }
+    }
+    nd.mnx[c] = mn[0], nd.mny[c] = mn[1], nd.mnz[c] = mn[2];
+    nd.mxx[c] = mx[0], nd.mxy[c] = mx[1], nd.mxz[c] = mx[2];
+    nd.child[c] = child;
+    nd.pad[c] = 0;
+  }
+  sub[me] = nd;
+  *depth = deepest + 1;
   return me;
 }
 
@@ -178,8 +217,9 @@ static int build_subtree(std::vector<BvhNode> &sub, std::vector<FacePts> &fp, in
 // reference's per-node re-sort of an already sorted sub-range is the identity for
 // a stable sort; one stable sort of the whole range reproduces it.  (thrust::sort
 // does not promise an order for equal keys; this build fixes it as stable.)
-static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<BvhNode> &sub, std::vector<FacePts> &fp,
-                           int first, int n, int leaf_max, int face_base) {
+static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<SubNode4> &sub, std::vector<FacePts> &fp,
+                           int first, int n, int leaf_max, int *sub_depth, int level = 0, int *ref_depth = nullptr) {
+  if (ref_depth && level + 1 > *ref_depth) *ref_depth = level + 1;
   BvhNode nd;
   for (int k = 0; k < 3; k++) nd.mn[k] = INFINITY, nd.mx[k] = -INFINITY;
   for (int i = 0; i < n; i++)  // bvh.cuh:71-82
@@ -195,14 +235,15 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<BvhNode> &su
   nodes.push_back(nd);
   if (n <= leaf_max) {
     // faces of this leaf get their final physical order inside build_subtree
-    nodes[me].left = build_subtree(sub, fp, first, n);
+    int d = 0;
+    nodes[me].left = build_subtree(sub, fp, first, n, &d);
     nodes[me].right = -n;
-    // sub-tree leaves index `faces` globally
+    *sub_depth = std::max(*sub_depth, d);
     return me;
   }
   int mid = (n - 1) / 2;
-  int l = build_bvh_nodes(nodes, sub, fp, first, mid + 1, leaf_max, face_base);
-  int r = build_bvh_nodes(nodes, sub, fp, first + mid + 1, n - mid - 1, leaf_max, face_base);
+  int l = build_bvh_nodes(nodes, sub, fp, first, mid + 1, leaf_max, sub_depth, level + 1, ref_depth);
+  int r = build_bvh_nodes(nodes, sub, fp, first + mid + 1, n - mid - 1, leaf_max, sub_depth, level + 1, ref_depth);
   nodes[me].left = l;
   nodes[me].right = r;
   return me;
@@ -213,6 +254,7 @@ std::string Scene::flatten() {
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
   n_pgrams = n_triangles = n_spheres = 0;
+  sub_depth = 0;
   if (!has_camera) return "scene has no camera";
   if (world.size() > 1024) return "world exceeds HitableList::kMaxHitables (1024)";
   if (cam.defocus) features |= F_DEFOCUS;
@@ -321,9 +363,15 @@ std::string Scene::flatten() {
         const int face_base = (int)faces.size();
         const int sub_base = (int)subnodes.size();
         BvhRec br{};
-        std::vector<BvhNode> local_nodes, local_sub;
+        std::vector<BvhNode> local_nodes;
+        std::vector<SubNode4> local_sub;
+        int depth = 0;
         // an empty mesh is a leaf that can never report a hit: it contributes nothing
-        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, local_sub, fp, 0, hb.n, leaf_max, face_base) : -1;
+        int ref_depth = 0;
+        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, local_sub, fp, 0, hb.n, leaf_max, &depth, 0, &ref_depth) : -1;
+        if (ref_depth + 1 > kRefStack) return "mesh tree too deep for the kernel's reference-tree stack";
+        sub_depth = std::max(sub_depth, depth);
+        if (3 * depth + 1 > kSubStack) return "mesh leaf too deep for the kernel's sub-tree stack";
         const int node_base = (int)nodes.size();
         for (BvhNode nd : local_nodes) {  // rebase indices into the scene-wide arrays
           if (nd.right < 0) {
@@ -333,11 +381,14 @@ std::string Scene::flatten() {
           }
           nodes.push_back(nd);
         }
-        for (BvhNode nd : local_sub) {
-          if (nd.right < 0) {
-            nd.left += face_base;
-          } else {
-            nd.left += sub_base, nd.right += sub_base;
+        for (SubNode4 nd : local_sub) {
+          for (int c = 0; c < 4; c++) {
+            if (nd.child[c] >= 0) {
+              nd.child[c] += sub_base;
+            } else {
+              const int enc = -(nd.child[c] + 1), cnt = enc & 7, first = enc >> 3;
+              nd.child[c] = cnt ? -((first + face_base) * 8 + cnt) - 1 : -1;
+            }
           }
           subnodes.push_back(nd);
         }

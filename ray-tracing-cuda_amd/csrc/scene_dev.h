@@ -71,17 +71,28 @@ struct TexRec {  // 32 B
   int64_t pad;
 };
 
-// Used for two trees.  (1) The reference's tree (bvh.cuh:113-121): exact bounds, median split of
-// the positions_[0].x-sorted faces, leaves of up to kMin faces; inner: left/right = child node
+// The reference's tree (bvh.cuh:113-121): exact bounds, median split of the
+// positions_[0].x-sorted faces, leaves of up to kMin faces; inner: left/right = child node
 // indices; leaf: left = root of the leaf's sub-tree in `subnodes`, right = -(face count).
-// (2) Per-leaf sub-trees (`subnodes`): conservative (padded) bounds over the leaf's faces;
-// inner: left/right = sub-node indices; leaf: left = first face, right = -(face count).
 struct BvhNode {  // 32 B
   float mn[3];
   float mx[3];
   int32_t left;
   int32_t right;  // negative marks a leaf
 };
+
+// Per-leaf sub-trees: 4-wide nodes with conservative (padded) child bounds, stored child-major
+// per plane so one 128-byte fetch (eight 16-byte loads) serves four slab tests.
+// child[i] >= 0: sub-node index; child[i] < 0: faces, encoded -(first*8 + count) - 1 with
+// count in 1..4; unused slots have an empty box (mn = +inf, mx = -inf) and count 0.
+struct alignas(16) SubNode4 {  // 128 B
+  float mnx[4], mny[4], mnz[4];
+  float mxx[4], mxy[4], mxz[4];
+  int32_t child[4];
+  int32_t pad[4];
+};
+constexpr int kSubStack = 32;  // per-lane sub-tree stack entries (LDS); 3 * depth + 1 must fit
+constexpr int kRefStack = 24;  // per-lane reference-tree stack entries (LDS); depth + 1 must fit
 
 struct BvhRec {  // one per BVH hitable
   int32_t root;      // node index
@@ -113,7 +124,7 @@ struct SceneDev {
   const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
   const BvhRec *bvhs;
   const BvhNode *nodes;
-  const BvhNode *subnodes;
+  const SubNode4 *subnodes;
   const FaceRec *faces;
   const float *face_uv;  // 6 floats per face or nullptr
   const MatRec *mats;
