@@ -1,0 +1,107 @@
+"""Edge cases of the trace path through the C ABI: worlds without Sky (a true miss is black,
+ray_tracing.cu:23-25), an empty world, an empty mesh, zero samples, a pitched texture upload."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oraclelib
+import rtmi
+from rtmi.scenes import v3, PI_D
+
+pytestmark = pytest.mark.gpu
+
+
+def both(fill, seed=5):
+    out = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        b = make(seed)
+        b.camera_pinhole(v3(0, 0.5, 3), v3(0, 0.3, 0), v3(0, 1, 0), PI_D / 3, 1.25)
+        fill(b)
+        out.append(b)
+    return out
+
+
+def render_both(fill, h=24, w=30, spp=3, depth=10, post=True):
+    import torch
+    o, p = both(fill)
+    o_rgb, o_rays, _, o_total = o.render(h, w, spp, depth, post=post)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth, post).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert R.total_rays() == o_total
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb)
+    return o_rgb, o_rays
+
+
+def test_world_without_sky_misses_are_black():
+    def fill(b):
+        b.sphere(v3(0, 0.3, 0), 0.5, b.lambertian(v3(0.8, 0.3, 0.3)))
+        b.parallelogram([v3(-1, 2, -1), v3(1, 2, -1), v3(-1, 2, 1)], b.diffuse_light(b.constant_texture(v3(3, 3, 3))))
+    rgb, rays = render_both(fill)
+    assert (rgb[0, 0] == 0).all() and rgb.max() > 0
+
+
+def test_empty_world():
+    rgb, rays = render_both(lambda b: None)
+    assert rgb.max() == 0 and (rays == 3).all()
+
+
+def test_empty_mesh_and_single_face_mesh():
+    def fill(b):
+        b.sky()
+        m = b.lambertian(v3(0.5, 0.5, 0.9))
+        b.bvh(np.zeros((0, 3, 3), dtype=np.float32), m)
+        b.bvh(np.array([[[-1, 0, 0], [1, 0, 0], [0, 1.5, 0]]], dtype=np.float32), m)
+    rgb, rays = render_both(fill)
+    assert (rays > 3).any()
+
+
+def test_zero_samples_writes_zeros():
+    import torch
+    p = rtmi.SceneBuilder(1)
+    p.camera_pinhole(v3(0, 0, 3), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+    p.sky()
+    p.commit()
+    R = rtmi.Renderer(p, 16, 16, 0, 10).init_rng()
+    R.tiles.fill_(7.0)
+    R.render()
+    torch.cuda.synchronize()
+    assert float(R.tiles.abs().max()) == 0.0 and R.total_rays() == 0
+
+
+def test_pitched_texture_rows():
+    """rtmi_image_texture honours pitch_bytes (cudaMemcpy2D semantics, scenes/birthday.cu:81-83)."""
+    import torch
+    from rtmi import scenes
+    tex = scenes.procedural_earthmap(16, 24)
+    padded = np.zeros((16, 40, 4), dtype=np.uint8)
+    padded[:, :24] = tex
+    padded[:, 24:] = 99  # padding bytes must never be sampled
+
+    def fill_o(b):
+        b.sky()
+        b.sphere(v3(0, 0.3, 0), 0.9, b.lambertian_tex(b.image_texture(tex)))
+
+    o = oraclelib.OracleBuilder(3)
+    o.camera_pinhole(v3(0, 0.5, 3), v3(0, 0.3, 0), v3(0, 1, 0), PI_D / 3, 1.0)
+    fill_o(o)
+    o_rgb, o_rays, _, _ = o.render(32, 32, 4, 10)
+    p = rtmi.SceneBuilder(3)
+    p.camera_pinhole(v3(0, 0.5, 3), v3(0, 0.3, 0), v3(0, 1, 0), PI_D / 3, 1.0)
+    p.sky()
+    L = rtmi.lib()
+    t = L.rtmi_image_texture(p.h, padded.ctypes.data_as(C.POINTER(C.c_uint8)), 16, 24, 40 * 4)
+    assert t >= 0
+    p.sphere(v3(0, 0.3, 0), 0.9, p.lambertian_tex(t))
+    p.commit()
+    R = rtmi.Renderer(p, 32, 32, 4, 10).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    rel = np.sqrt(((img.cpu().numpy() - o_rgb) ** 2).sum() / (o_rgb ** 2).sum())
+    assert rel <= 1e-3
