@@ -421,9 +421,19 @@ static void rt_gather(RtComm *c, const float *d_send, float *d_recv_root, size_t
 }
 
 // ---------------------------------------------------------------- the two entry points
+// Sum-reduce `count` floats to rank 0 in place on the root (MPI_Reduce(SUM) of utils.cu:124-125).
+static void rt_reduce_sum(RtComm *c, float *d_buf, size_t count, hipStream_t stream) {
+  if (c->world <= 1) return;
+  CHECK(ncclReduce(d_buf, d_buf, count, ncclFloat, ncclSum, 0, c->comm, stream) == ncclSuccess);
+}
+
+// spp_split: the reference's decomposition (utils.cu:189,220,238) — every rank renders the WHOLE
+// frame with GetWorkload(rank, world, spp) samples and no post-process, frames are summed on rank 0
+// and the root applies sqrt(clamp(sum / spp)).  All ranks seed identically, as the reference does
+// (quirk g11), so this mode reproduces its multi-rank image rather than a better one.
 static void rt_run(curandState **d_states, Camera **d_camera, HitableList **d_world, glm::vec3 **d_image,
                    nvstd::function<void(HitableList *, Camera *)> &init_world, int height, int width, int spp,
-                   uint64_t seed, RtComm *comm) {
+                   uint64_t seed, RtComm *comm, bool spp_split = false) {
   const bool overridden = std::getenv("RT_WIDTH") || std::getenv("RT_HEIGHT");
   height = env_int("RT_HEIGHT", height);
   width = env_int("RT_WIDTH", width);
@@ -438,7 +448,14 @@ static void rt_run(curandState **d_states, Camera **d_camera, HitableList **d_wo
   RT_HIP(hipMalloc((void **)d_world, sizeof(HitableList)));
   RT_HIP(hipMalloc((void **)d_camera, sizeof(Camera)));
 
+  const int total_spp = spp;
   rtmi_frame frame{height, width, spp, max_depth, 1, comm->rank, comm->world};
+  if (spp_split) {
+    frame.spp = GetWorkload(comm->rank, comm->world, total_spp);
+    frame.post_process = 0;
+    frame.rank = 0, frame.world_size = 1;  // every rank owns the whole frame
+    LOG(INFO) << "[" << comm->rank << " / " << comm->world << "] workload: " << frame.spp;
+  }
   // the scene may draw from any d_states[i] during init_world, so every pixel's state is made
   // available in the scene's layout (rank-independent: a single-shard frame covers all pixels)
   rtmi_frame whole = frame;
@@ -473,7 +490,8 @@ static void rt_run(curandState **d_states, Camera **d_camera, HitableList **d_wo
   hipLaunchKernelGGL(rt_states_to_soa, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, 0, frame, d_my_pixel_of,
                      items, *d_states, d_soa);
   float *d_tiles = dev_alloc<float>((size_t)items * 3);
-  float *d_all = comm->rank == 0 && comm->world > 1 ? dev_alloc<float>((size_t)items * 3 * comm->world) : d_tiles;
+  float *d_all =
+      !spp_split && comm->rank == 0 && comm->world > 1 ? dev_alloc<float>((size_t)items * 3 * comm->world) : d_tiles;
   RT_HIP(hipDeviceSynchronize());
 
   {
@@ -492,13 +510,18 @@ static void rt_run(curandState **d_states, Camera **d_camera, HitableList **d_wo
               << " rays, " << (rays / (ms * 1e3)) << " Mrays/s)";
   }
 
-  if (comm->world > 1) {
+  if (spp_split) {
+    rt_reduce_sum(comm, d_tiles, (size_t)items * 3, nullptr);
+    RT_HIP(hipDeviceSynchronize());
+  } else if (comm->world > 1) {
     if (comm->rank == 0) RT_HIP(hipMemcpy(d_all, d_tiles, (size_t)items * 3 * sizeof(float), hipMemcpyDeviceToDevice));
     rt_gather(comm, d_tiles, d_all, (size_t)items * 3, nullptr);
     RT_HIP(hipDeviceSynchronize());
   }
   if (comm->rank == 0) {
-    RT_ABI(rtmi_untile(&frame, d_all, reinterpret_cast<float *>(*d_image), nullptr));
+    RT_ABI(rtmi_untile(&frame, spp_split ? d_tiles : d_all, reinterpret_cast<float *>(*d_image), nullptr));
+    if (spp_split)  // GatherImageData's root-side step (utils.cu:126-129)
+      RT_ABI(rtmi_post_process(reinterpret_cast<float *>(*d_image), (int64_t)n_pixels, total_spp, nullptr));
     std::vector<glm::vec3> image(n_pixels);
     RT_HIP(hipMemcpy(image.data(), *d_image, sizeof(glm::vec3) * n_pixels, hipMemcpyDeviceToHost));
     if (const char *dump = std::getenv("RT_DUMP")) {
@@ -527,13 +550,17 @@ __host__ void Main(curandState **d_states, Camera **d_camera, HitableList **d_wo
 // samples of every pixel over the ranks and sum-reduces full frames on the host; here the ranks
 // split the PIXELS (interleaved 8x8 tiles), each pixel gets all its samples on one GPU, and the
 // only exchange is an RCCL gather of the tile buffers to rank 0 — the frame equals the
-// single-process frame for any number of ranks.
+// single-process frame for any number of ranks.  RT_DIST_MODE=spp selects the reference's own
+// decomposition instead (sample split + sum-reduce + root post-process).
 __host__ void DistributedMain(curandState **d_states, Camera **d_camera, HitableList **d_world, glm::vec3 **d_image,
                               nvstd::function<void(HitableList *world, Camera *camera)> init_world, int height,
                               int width, int spp) {
   RtComm comm;
   rt_comm_init(&comm);
-  LOG(INFO) << "[" << comm.rank << " / " << comm.world << "] pixel-tile shard, spp " << spp;
-  rt_run(d_states, d_camera, d_world, d_image, init_world, height, width, spp, 10086, &comm);
+  const char *mode = std::getenv("RT_DIST_MODE");
+  const bool spp_split = mode && std::string(mode) == "spp";
+  LOG(INFO) << "[" << comm.rank << " / " << comm.world << "] " << (spp_split ? "sample split (reference mode)" : "pixel-tile shard")
+            << ", spp " << spp;
+  rt_run(d_states, d_camera, d_world, d_image, init_world, height, width, spp, 10086, &comm, spp_split);
   if (comm.comm) ncclCommDestroy(comm.comm);
 }

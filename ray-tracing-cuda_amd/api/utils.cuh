@@ -7,7 +7,9 @@
 //
 // Run-time overrides (the reference bakes these in at compile time): RT_WIDTH, RT_HEIGHT,
 // RT_SPP, RT_MAX_DEPTH (default 10 = TRACE_DEPTH_LIMIT, ray_tracing.cu:10), RT_SEED,
-// RT_OUTPUT (default image.jpeg), RT_DUMP (also write the float32 H*W*3 frame to this path).
+// RT_OUTPUT (default image.jpeg), RT_DUMP (also write the float32 H*W*3 frame to this path),
+// RT_DIST_MODE=spp (DistributedMain only: the reference's sample split + sum-reduce instead of
+// pixel-tile shards).
 #include <cuda_runtime.h>
 #include <curand_kernel.h>
 #include <mpi.h>

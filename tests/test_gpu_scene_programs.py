@@ -91,3 +91,14 @@ def test_run_time_overrides_and_determinism(tmp_path):
     b, _ = run_scene("cornell_box", tmp_path / "b", 40, 40, 3, depth=5, extra_env={"RT_SEED": "7"})
     c, _ = run_scene("cornell_box", tmp_path / "b", 40, 40, 3, depth=5, extra_env={"RT_SEED": "8"})
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_reference_sample_split_mode_single_rank(tmp_path):
+    """RT_DIST_MODE=spp with one rank: raw sums + root-side sqrt(clamp(sum/spp)) must equal the
+    kernel's own post-process (utils.cu:126-129 vs ray_tracing.cu:78-83)."""
+    (tmp_path / "a").mkdir()
+    (tmp_path / "b").mkdir()
+    a, _ = run_scene("spheres", tmp_path / "a", 40, 48, 3)
+    b, log = run_scene("spheres", tmp_path / "b", 40, 48, 3, extra_env={"RT_DIST_MODE": "spp"})
+    assert "sample split" in log
+    assert np.array_equal(a, b)
