@@ -190,6 +190,12 @@ int rtmi_get_workload(int rank, int world_size, int spp);
 
 /* Kernel launch configuration knobs (0 = library default). */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
+/* Work-queue order of rtmi_render: 0 = tiles in image order; 1 (default) = longest-first when it
+ * can pay (a 2-spp probe on scratch RNG states estimates each tile's cost; pixels are indivisible
+ * serial chains, so starting the expensive ones first shortens the end-of-frame tail); 2 = always
+ * longest-first.  Never changes any pixel's value.  Scheduler scratch is cached in the scene:
+ * concurrent rtmi_render calls on ONE scene from several threads are not supported. */
+int rtmi_set_schedule(int mode);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ static int hip_fail(hipError_t e, const char *what) {
   } while (0)
 
 static int g_blocks_per_cu = 0, g_threads = 0;
+static int g_schedule = 1;  // 0: image order, 1: longest-first when it can pay, 2: always longest-first
 
 static Scene *S(rtmi_scene *s) { return reinterpret_cast<Scene *>(s); }
 static const Scene *S(const rtmi_scene *s) { return reinterpret_cast<const Scene *>(s); }
@@ -99,6 +100,9 @@ int rtmi_device_count(void) {
 rtmi_scene *rtmi_scene_create(void) { return reinterpret_cast<rtmi_scene *>(new Scene()); }
 
 static void free_device(Scene *s) {
+  if (s->d_sched) (void)hipFree(s->d_sched);
+  s->d_sched = nullptr;
+  s->sched_bytes = 0;
   for (void *p : s->dev_allocs) (void)hipFree(p);
   s->dev_allocs.clear();
   s->d_counters = nullptr;
@@ -468,9 +472,40 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   int64_t cap = (int64_t)n_cu * per_cu;
   int blocks = (int)(want < cap ? want : cap);
   if (blocks < 1) blocks = 1;
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), (hipStream_t)stream));
+  hipStream_t st = (hipStream_t)stream;
+  // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
+  // tile is long enough for the 2-spp probe to be cheap.
+  const uint32_t *d_order = nullptr;
+  const int probe_spp = 2;
+  const bool many_tiles = (int64_t)d.local_tiles * 64 > (int64_t)blocks * threads;
+  if (g_schedule == 2 || (g_schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
+    Scene *ms = const_cast<Scene *>(s);  // scheduler scratch is a cache, not scene state
+    const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
+    const size_t need = n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 64;
+    if (ms->sched_bytes < need) {
+      if (ms->d_sched) (void)hipFree(ms->d_sched);
+      ms->d_sched = nullptr, ms->sched_bytes = 0;
+      HIP_TRY(hipMalloc(&ms->d_sched, need));
+      ms->sched_bytes = need;
+    }
+    uint32_t *p_states = reinterpret_cast<uint32_t *>(ms->d_sched);
+    uint32_t *p_rays = p_states + n * RTMI_STATE_WORDS;
+    uint32_t *p_cost = p_rays + n;
+    uint32_t *p_order = p_cost + nt;
+    uint32_t *p_max = p_order + nt;
+    HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    FrameDev probe = d;
+    probe.spp = probe_spp;
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), st));
+    // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
+    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, true, blocks,
+                          threads, st));
+    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, st));
+    d_order = p_order;
+  }
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
-                        s->d_counters, blocks, threads, (hipStream_t)stream));
+                        s->d_counters, d_order, false, blocks, threads, st));
   return RTMI_OK;
 }
 
@@ -504,6 +539,11 @@ int rtmi_post_process(float *d_image, int64_t n_pixels, int spp, void *stream) {
 }
 int rtmi_get_workload(int rank, int world_size, int spp) {
   return spp / world_size + (int)(rank < (spp % world_size));  // utils.cu:111-113
+}
+int rtmi_set_schedule(int mode) {
+  if (mode < 0 || mode > 2) return fail(RTMI_ERR_INVALID, "schedule mode must be 0 (image order), 1 (auto) or 2 (always longest-first)");
+  g_schedule = mode;
+  return RTMI_OK;
 }
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block) {
   if (blocks_per_cu < 0 || threads_per_block < 0 || (threads_per_block % 64) != 0 || threads_per_block > 256)

@@ -523,13 +523,14 @@ struct LaunchCfg {
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
   int32_t substack_off;  // byte offset of the per-lane sub-tree stacks (BVH variants)
   int32_t pad[2];
+  const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
 };
 
 template <uint32_t F>
-__global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
-                                                      uint32_t *__restrict__ states, float *__restrict__ out,
-                                                      uint32_t *__restrict__ ray_counts,
-                                                      unsigned long long *__restrict__ counters) {
+__device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &fr, const LaunchCfg &lc,
+                                            uint32_t *__restrict__ states, float *__restrict__ out,
+                                            uint32_t *__restrict__ ray_counts,
+                                            unsigned long long *__restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
   uint8_t *stack8 = smem + lc.stack_off;
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
           break;
         }
         q = (int64_t)nq;
+        if (lc.tile_order) q = (int64_t)lc.tile_order[nq >> 6] * 64 + (int64_t)(nq & 63);
         int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
         if (idx < 0 || fr.spp <= 0) {  // ragged-tile padding (or nothing to sample)
           out[q * 3 + 0] = 0.f, out[q * 3 + 1] = 0.f, out[q * 3 + 2] = 0.f;
@@ -808,6 +810,23 @@ __global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, L
   if ((threadIdx.x & 63) == 0 && ray_total) atomicAdd(&counters[1], ray_total);
 }
 
+// The trace kernel proper, and the same code under a second name for the scheduler's 2-spp
+// cost probe (so per-kernel profiles keep the two apart).
+template <uint32_t F>
+__global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+                                                      uint32_t *__restrict__ states, float *__restrict__ out,
+                                                      uint32_t *__restrict__ ray_counts,
+                                                      unsigned long long *__restrict__ counters) {
+  render_body<F>(sc, fr, lc, states, out, ray_counts, counters);
+}
+template <uint32_t F>
+__global__ __launch_bounds__(256) void probe_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+                                                     uint32_t *__restrict__ states, float *__restrict__ out,
+                                                     uint32_t *__restrict__ ray_counts,
+                                                     unsigned long long *__restrict__ counters) {
+  render_body<F>(sc, fr, lc, states, out, ray_counts, counters);
+}
+
 // ------------------------------------------------------------------ untile / post
 template <typename E, int C>
 __global__ __launch_bounds__(256) void untile_kernel(FrameDev fr, const E *__restrict__ tiles, E *__restrict__ image) {
@@ -828,6 +847,65 @@ __global__ __launch_bounds__(256) void post_kernel(float *__restrict__ img, int6
   img[g] = sqrtf(clamp1(img[g] / (float)spp, 0.f, 1.f));  // utils.cu:127-128
 }
 
+// ------------------------------------------------------------------ longest-first tile order
+// A pixel is an indivisible serial chain (its samples share one RNG stream), so the end of a
+// frame is a tail of lanes finishing their last pixel.  Handing out the expensive tiles first
+// shortens that tail (longest-processing-time-first).  Cost estimate: rays per tile measured by
+// a 2-spp probe pass on a scratch copy of the RNG states.  The order only changes which lane
+// renders which pixel when; every pixel's arithmetic is unchanged.
+__global__ __launch_bounds__(256) void tile_cost_kernel(const uint32_t *__restrict__ ray_counts, int n_tiles,
+                                                         uint32_t *__restrict__ cost, uint32_t *__restrict__ max_cost) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const uint4 *p = reinterpret_cast<const uint4 *>(ray_counts + (size_t)t * 64);
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; i++) {
+    uint4 v = p[i];
+    s += v.x + v.y + v.z + v.w;
+  }
+  cost[t] = s;
+  atomicMax(max_cost, s);
+}
+
+// One workgroup: counting sort of the tiles into 256 cost buckets, most expensive bucket first.
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost,
+                                                          const uint32_t *__restrict__ max_cost, int n_tiles,
+                                                          uint32_t *__restrict__ order) {
+  __shared__ uint32_t bins[256];
+  __shared__ uint32_t base[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) bins[i] = 0;
+  __syncthreads();
+  const uint32_t mx = *max_cost > 0 ? *max_cost : 1;
+  for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    uint32_t b = 255u - (uint32_t)(((unsigned long long)cost[t] * 255ull) / mx);  // bucket 0 = most expensive
+    atomicAdd(&bins[b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; i++) {
+      base[i] = run;
+      run += bins[i];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
+    uint32_t b = 255u - (uint32_t)(((unsigned long long)cost[t] * 255ull) / mx);
+    order[atomicAdd(&base[b], 1u)] = (uint32_t)t;
+  }
+}
+
+hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
+                             uint32_t *d_order, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
+                     d_max);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -841,6 +919,7 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
 
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
   LaunchCfg lc{};
+  lc.tile_order = nullptr;
   lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
   lc.wide_ids = sc.n_mats > 256 ? 1 : 0;
   size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
@@ -857,12 +936,18 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
 
 template <uint32_t F>
 static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
-                                  uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
-                                  hipStream_t stream) {
+                                  uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
+                                  bool probe, int blocks, int threads, hipStream_t stream) {
   size_t lds = 0;
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
-  hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
-                     d_ray_counts, d_counters);
+  lc.tile_order = d_tile_order;
+  if (probe) {
+    hipLaunchKernelGGL(probe_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
+                       d_ray_counts, d_counters);
+  } else {
+    hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
+                       d_ray_counts, d_counters);
+  }
   return hipGetLastError();
 }
 
@@ -902,11 +987,12 @@ int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, i
 }
 
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
-                         uint32_t *d_ray_counts, unsigned long long *d_counters, int blocks, int threads,
-                         hipStream_t stream) {
+                         uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
+                         bool probe, int blocks, int threads, hipStream_t stream) {
 #define X(V) \
   if (variant == (uint32_t)(V)) \
-    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, blocks, threads, stream);
+    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, d_tile_order, probe, blocks, \
+                                threads, stream);
   RTMI_FOR_EACH_VARIANT(X)
 #undef X
   return hipErrorInvalidValue;

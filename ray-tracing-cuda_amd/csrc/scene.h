@@ -74,6 +74,9 @@ struct Scene {
   unsigned long long *d_counters = nullptr;  // [0] work queue head, [1] total rays
   int device = -1;
   int64_t bytes_per_ray = 0;
+  // scratch of the longest-first scheduler (probe states, probe ray counts, costs, order)
+  void *d_sched = nullptr;
+  size_t sched_bytes = 0;
 
   // host-only flatten (no HIP calls); returns "" or an error message
   std::string flatten();

@@ -83,6 +83,7 @@ SYMBOLS = [
     ("rtmi_post_process", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     ("rtmi_get_workload", C.c_int, [C.c_int, C.c_int, C.c_int]),
     ("rtmi_set_launch", C.c_int, [C.c_int, C.c_int]),
+    ("rtmi_set_schedule", C.c_int, [C.c_int]),
 ]
 
 

@@ -218,3 +218,22 @@ def test_c1_spheres_full_config():
     g = common.gpu_render("spheres", 256, 256, 16, 8)
     o = common.oracle_render("spheres", 256, 256, 16, 8)
     assert_parity("C1", g[:4], o[:4])
+
+
+def test_longest_first_schedule_does_not_change_the_frame():
+    """rtmi_set_schedule: the work-queue order (image order vs longest-first via the 2-spp probe)
+    must not change a single bit of the image, the ray counts or the final RNG states."""
+    import rtmi
+    L = rtmi.lib()
+    try:
+        L.rtmi_set_schedule(0)
+        a = common.gpu_render("cornell_box", 96, 128, 64, 10)
+        L.rtmi_set_schedule(2)
+        b = common.gpu_render("cornell_box", 96, 128, 64, 10)
+        c = common.gpu_render("cornell_box", 96, 128, 64, 10, world_size=3)
+    finally:
+        L.rtmi_set_schedule(1)
+    for other in (b, c):
+        assert np.array_equal(a[0], other[0]) and np.array_equal(a[1], other[1]) and a[3] == other[3]
+    assert np.array_equal(gpu_states_rowmajor(a[2], 96, 128), gpu_states_rowmajor(b[2], 96, 128))
+    assert L.rtmi_set_schedule(7) < 0
