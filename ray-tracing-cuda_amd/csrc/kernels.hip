@@ -240,23 +240,22 @@ __device__ __forceinline__ V3 ball_sample(Rng &rng, float &sum) {
 // Conservative "does the segment [lo, hi] of the ray come anywhere near this box" test, used
 // (a) on the padded sub-tree nodes and (b) as a cheap pre-reject in front of the reference's
 // exact AABB::Hit: if the ray never touches the box inflated by `pad`, no plane-crossing point
-// can lie on its surface.  Slack is applied on every comparison; NaNs cannot cause a cull.
-__device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V3 d, V3 inv_d, float lo, float hi) {
-  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z}, ii[3] = {inv_d.x, inv_d.y, inv_d.z};
-  bool miss = false;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    const float mn = nd.mn[a] - pad, mx = nd.mx[a] + pad;
-    if (dd[a] == 0.f) {
-      miss = miss || (oo[a] < mn) || (oo[a] > mx);
-    } else {
-      float t0 = (mn - oo[a]) * ii[a], t1 = (mx - oo[a]) * ii[a];
-      float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
-      lo = fmaxf(lo, tn - fabsf(tn) * 1e-5f);
-      hi = fminf(hi, tf + fabsf(tf) * 1e-5f);
-    }
-  }
-  return !(miss || lo > hi);
+// can lie on its surface.  `inv_d` is the clamped reciprocal of safe_inverse(): finite, so no
+// 0 * inf NaN can appear and a zero direction component needs no branch (an origin outside the
+// slab then yields two huge same-sign crossings, i.e. a miss; inside, a huge interval).  The
+// relative slack is applied once to the merged entry/exit (t - |t| eps is monotone in t).
+__device__ __forceinline__ float safe_inverse(float x) {
+  return fabsf(x) < 1e-30f ? copysignf(1e30f, x) : 1.0f / x;
+}
+__device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V3 inv_d, float lo, float hi) {
+  const float t0x = (nd.mn[0] - pad - o.x) * inv_d.x, t1x = (nd.mx[0] + pad - o.x) * inv_d.x;
+  const float t0y = (nd.mn[1] - pad - o.y) * inv_d.y, t1y = (nd.mx[1] + pad - o.y) * inv_d.y;
+  const float t0z = (nd.mn[2] - pad - o.z) * inv_d.z, t1z = (nd.mx[2] + pad - o.z) * inv_d.z;
+  const float enter = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+  const float leave = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+  lo = fmaxf(lo, enter - fabsf(enter) * 1e-5f);
+  hi = fminf(hi, leave + fabsf(leave) * 1e-5f);
+  return lo <= hi;
 }
 
 struct Hit {
@@ -381,7 +380,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
     }
     if ((F & F_BVH) && run.kind == RUN_BVH) {
       // Slab-test operands, once per ray (used only by the conservative sub-trees).
-      const V3 inv_d = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+      const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
         // bvh.cuh:123-158 as an explicit depth-first walk: the left subtree first,
@@ -411,7 +410,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
             float ext = fmaxf(fmaxf(nd.mx[0] - nd.mn[0], nd.mx[1] - nd.mn[1]), nd.mx[2] - nd.mn[2]);
             float mag = fmaxf(fmaxf(fmaxf(fabsf(nd.mn[0]), fabsf(nd.mx[0])), fmaxf(fabsf(nd.mn[1]), fabsf(nd.mx[1]))),
                               fmaxf(fabsf(nd.mn[2]), fabsf(nd.mx[2])));
-            if (!slab_touch(nd, 1e-4f * ext + 1e-5f * mag + 1e-30f, o, d, inv_d, T_FROM_F * 0.999f,
+            if (!slab_touch(nd, 1e-4f * ext + 1e-5f * mag + 1e-30f, o, inv_d, T_FROM_F * 0.999f,
                             (float)bt_to * 1.0001f + 1e-6f))
               continue;
             if (!aabb_test<T>(nd, o, d, bt_to)) continue;
@@ -455,7 +454,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                 bx.mn[0] = cmnx[c], bx.mn[1] = cmny[c], bx.mn[2] = cmnz[c];
                 bx.mx[0] = cmxx[c], bx.mx[1] = cmxy[c], bx.mx[2] = cmxz[c];
                 // an unused slot has mn = +inf, mx = -inf and fails the test
-                if (cch[c] != -1 && slab_touch(bx, 0.f, o, d, inv_d, lo0, hi0)) sstack[(stop++) * sst] = cch[c];
+                if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * sst] = cch[c];
               }
             } else {
               // <= 4 faces: all records (3 x 16 B each) are fetched before any test so the
