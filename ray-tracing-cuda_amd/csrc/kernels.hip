@@ -379,70 +379,52 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       }
     }
     if ((F & F_BVH) && run.kind == RUN_BVH) {
-      // Slab-test operands, once per ray (used only by the conservative sub-trees).
+      // BVH::Hit (bvh.cuh:123-183) answered without walking the reference's tree.
+      //
+      // What the reference computes: a depth-first walk, left subtree first, with a running
+      // t_to; a child is entered iff AABB::Hit(child box, [t_from, t_to]) holds at that moment
+      // (the root's box is never tested); an entered leaf scans its faces in order, accepts
+      // every t_from <= t <= t_to and lowers t_to to it; the last acceptance is the answer.
+      // Hence (DESIGN.md "Mesh queries"):
+      //  * a leaf's contribution at running bound T is its best face -- smallest t, highest
+      //    reference index among equal t -- provided that t <= T; it does not depend on T
+      //    otherwise, nor on the order the faces are looked at;
+      //  * leaves without a hit change nothing; whether their boxes were entered is irrelevant;
+      //  * a box test is only ever needed on the root-to-leaf path of a leaf that holds a hit,
+      //    and it sees the t_to left by the hit leaves before it in visiting order.
+      // So: (1) one search of the mesh-wide 4-wide tree collects, per reference leaf, the best
+      // face (a small per-lane list keyed by the leaf's path code); (2) the listed leaves are
+      // replayed in visiting order, evaluating the reference's exact box test on the path nodes
+      // not shared with the previously replayed leaf.  If more leaves hold hits than the list
+      // has slots, the leaves beyond `cut` are left to a further search pass.
       const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
+      const int nthr = blockDim.x;
+      int *sstack = s_substack + threadIdx.x;                                // [level][thread]
+      int *hits = s_substack + (size_t)kSubStack * nthr + threadIdx.x;       // [slot][word][thread]
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
-        // bvh.cuh:123-158 as an explicit depth-first walk: the left subtree first,
-        // then the right child's box is tested against the t_to the left subtree
-        // left behind; any accepted face (t <= t_to, inclusive) replaces the record.
-        // The root's own box is never tested (bvh.cuh:175-177).
-        // reference-tree stack: LDS, [level][thread], above the sub-tree stack's kSubStack levels
-        int *stack = s_substack + (size_t)kSubStack * blockDim.x + threadIdx.x;
-        const int rst = blockDim.x;
-        int top = 0;
-        stack[(top++) * rst] = br.root;
-        bool first = true;
         T bt_to = t_to;
         bool bhit = false;
         int bface = 0;
         float fu = 0.f, fv = 0.f;
-        while (top > 0) {
-          int ni = stack[(--top) * rst];
-          BvhNode nd;
-          if (ni < lds_nodes) {
-            nd = s_nodes[ni];
-          } else {
-            nd = sc.nodes[ni];
-          }
-          if (!first) {
-            // cheap conservative reject, then the reference's exact surface-crossing test
-            float ext = fmaxf(fmaxf(nd.mx[0] - nd.mn[0], nd.mx[1] - nd.mn[1]), nd.mx[2] - nd.mn[2]);
-            float mag = fmaxf(fmaxf(fmaxf(fabsf(nd.mn[0]), fabsf(nd.mx[0])), fmaxf(fabsf(nd.mn[1]), fabsf(nd.mx[1]))),
-                              fmaxf(fabsf(nd.mn[2]), fabsf(nd.mx[2])));
-            if (!slab_touch(nd, 1e-4f * ext + 1e-5f * mag + 1e-30f, o, inv_d, T_FROM_F * 0.999f,
-                            (float)bt_to * 1.0001f + 1e-6f))
-              continue;
-            if (!aabb_test<T>(nd, o, d, bt_to)) continue;
-          }
-          first = false;
-          if (nd.right >= 0) {
-            stack[(top++) * rst] = nd.right;
-            stack[(top++) * rst] = nd.left;
-            continue;
-          }
-          // ---- leaf query (bvh.cuh:125-136): among this leaf's faces accepted with
-          // t_from <= t <= bt_to keep the smallest t, the highest reference index among equal
-          // t — what the reference's in-order scan with `t <= t_to` ends with.  The faces are
-          // reached through a padded sub-tree instead of a scan of up to 2048 of them.
-          T best = bt_to;
-          bool have = false;
-          int best_face = 0, best_orig = -1;
-          float lu = 0.f, lv = 0.f;
-          // sub-tree stack in LDS, [level][thread] (a register array indexed per lane turns
-          // into select chains); entries >= 0 are 4-wide nodes, < 0 encoded face ranges
-          const int sst = blockDim.x;
-          int *sstack = s_substack + threadIdx.x;
+        // replay state: path code of the last replayed leaf and, left-aligned like the code,
+        // one bit per level "that node of its path was entered"
+        bool have_prev = false;
+        uint32_t prev_code = 0u, entered = 0u;
+        int64_t lo_code = 0, cut = (int64_t)1 << 32;
+        for (;;) {
+          // ---- (1) search: best face per leaf with lo_code <= code < cut, t <= bt_to
+          int cnt = 0;
           int stop = 0;
-          sstack[(stop++) * sst] = nd.left;
+          sstack[(stop++) * nthr] = br.sub_root;
+          const float lo0 = T_FROM_F * 0.999f, hi0 = (float)bt_to * 1.0001f + 1e-6f;
           while (stop > 0) {
-            const int e = sstack[(--stop) * sst];
+            const int e = sstack[(--stop) * nthr];
             if (e >= 0) {
               // one 128-byte node: four padded child boxes (plane-major) + four child references
               const float4 *np4 = reinterpret_cast<const float4 *>(sc.subnodes + e);
               const float4 mnx = np4[0], mny = np4[1], mnz = np4[2], mxx = np4[3], mxy = np4[4], mxz = np4[5];
               const float4 chf = np4[6];
-              const float lo0 = T_FROM_F * 0.999f, hi0 = (float)best * 1.0001f + 1e-6f;
               const float cmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, cmny[4] = {mny.x, mny.y, mny.z, mny.w},
                           cmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, cmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w},
                           cmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, cmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
@@ -454,41 +436,136 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                 bx.mn[0] = cmnx[c], bx.mn[1] = cmny[c], bx.mn[2] = cmnz[c];
                 bx.mx[0] = cmxx[c], bx.mx[1] = cmxy[c], bx.mx[2] = cmxz[c];
                 // an unused slot has mn = +inf, mx = -inf and fails the test
-                if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * sst] = cch[c];
+                if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * nthr] = cch[c];
               }
             } else {
               // <= 4 faces: all records (3 x 16 B each) are fetched before any test so the
               // memory round trips overlap; `faces` carries 4 records of padding
-              const int enc = -(e + 1), cnt = enc & 7, first = enc >> 3;
+              const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
               const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + first);
               float4 q[12];
 #pragma unroll
               for (int w = 0; w < 12; w++) q[w] = fp4[w];
 #pragma unroll
               for (int fi = 0; fi < 4; fi++) {
-                if (fi < cnt) {
+                if (fi < fcnt) {
                   const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
                   float t = 0.f, u = 0.f, v = 0.f;
-                  if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, best, t, u, v)) {
-                    const int orig = __float_as_int(c.y);
-                    if ((T)t < best || !have || orig > best_orig) {  // t <= best holds here
-                      best = (T)t;
-                      have = true;
-                      best_face = first + fi;
-                      best_orig = orig;
-                      lu = u, lv = v;
+                  if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, bt_to, t, u, v)) {
+                    const uint32_t code = (uint32_t)__float_as_int(c.z);
+                    if ((int64_t)code >= lo_code && (int64_t)code < cut) {
+                      int found = -1, jmax = 0;
+                      uint32_t cmax = 0u;
+                      for (int j = 0; j < cnt; j++) {
+                        const uint32_t cj = (uint32_t)hits[(j * kHitWords + 0) * nthr];
+                        if (cj == code) found = j;
+                        if (cj >= cmax) cmax = cj, jmax = j;
+                      }
+                      int slot = -1;
+                      if (found >= 0) {
+                        // same leaf: smaller t wins, the higher reference index among equal t
+                        T tj;
+                        if (DT) {
+                          tj = (T)__hiloint2double(hits[(found * kHitWords + 3) * nthr],
+                                                   hits[(found * kHitWords + 2) * nthr]);
+                        } else {
+                          tj = (T)__int_as_float(hits[(found * kHitWords + 2) * nthr]);
+                        }
+                        bool better = (T)t < tj;
+                        if ((T)t == tj)
+                          better = __float_as_int(c.y) > sc.faces[hits[(found * kHitWords + 1) * nthr]].orig;
+                        if (better) slot = found;
+                      } else if (cnt < kHitSlots) {
+                        slot = cnt++;
+                      } else if (code > cmax) {
+                        cut = (int64_t)code;  // this leaf and everything after it: next pass
+                      } else {
+                        cut = (int64_t)cmax;  // drop the last listed leaf instead
+                        slot = jmax;
+                      }
+                      if (slot >= 0) {
+                        hits[(slot * kHitWords + 0) * nthr] = (int)code;
+                        hits[(slot * kHitWords + 1) * nthr] = first + fi;
+                        if (DT) {
+                          const double td = (double)(T)t;
+                          hits[(slot * kHitWords + 2) * nthr] = __double2loint(td);
+                          hits[(slot * kHitWords + 3) * nthr] = __double2hiint(td);
+                        } else {
+                          hits[(slot * kHitWords + 2) * nthr] = __float_as_int(t);
+                        }
+                      }
                     }
                   }
                 }
               }
             }
           }
-          if (have) {
-            bt_to = best;
-            bhit = true;
-            bface = best_face;
-            fu = lu, fv = lv;
+          // ---- (2) replay the listed leaves in the reference's visiting order
+          int64_t last = -1;
+          for (int k = 0; k < cnt; k++) {
+            int sel = -1;
+            uint32_t code = 0xffffffffu;
+            for (int j = 0; j < cnt; j++) {
+              const uint32_t cj = (uint32_t)hits[(j * kHitWords + 0) * nthr];
+              if ((int64_t)cj > last && (int64_t)cj < cut && cj <= code) code = cj, sel = j;
+            }
+            if (sel < 0) break;  // the rest was pushed beyond `cut`
+            last = (int64_t)code;
+            const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
+            uint32_t bits = shared ? entered & (0xffffffffu << (32 - shared)) : 0u;
+            int ni = br.root;
+            bool ent = true;
+            for (int lvl = 1;; lvl++) {
+              int left, right;
+              if (ni < lds_nodes) {
+                left = s_nodes[ni].left, right = s_nodes[ni].right;
+              } else {
+                left = sc.nodes[ni].left, right = sc.nodes[ni].right;
+              }
+              if (right < 0) break;  // ni is the leaf, and every box on the way was entered
+              const uint32_t bit = 0x80000000u >> (lvl - 1);
+              ni = (code & bit) ? right : left;
+              if (lvl <= shared) {
+                ent = (bits & bit) != 0u;
+              } else {
+                BvhNode nd;
+                if (ni < lds_nodes) {
+                  nd = s_nodes[ni];
+                } else {
+                  nd = sc.nodes[ni];
+                }
+                ent = aabb_test<T>(nd, o, d, bt_to);
+                if (ent) bits |= bit;
+              }
+              if (!ent) break;
+            }
+            have_prev = true;
+            prev_code = code;
+            entered = bits;
+            if (ent) {
+              T tj;
+              if (DT) {
+                tj = (T)__hiloint2double(hits[(sel * kHitWords + 3) * nthr], hits[(sel * kHitWords + 2) * nthr]);
+              } else {
+                tj = (T)__int_as_float(hits[(sel * kHitWords + 2) * nthr]);
+              }
+              if (tj <= bt_to) {
+                bt_to = tj;
+                bhit = true;
+                bface = hits[(sel * kHitWords + 1) * nthr];
+              }
+            }
           }
+          if (cut >> 32) break;  // nothing was deferred
+          lo_code = cut;
+          cut = (int64_t)1 << 32;
+        }
+        if (bhit && (F & F_TEX)) {
+          // barycentrics of the winner (the same binary32 operations as in the search)
+          const FaceRec f = sc.faces[bface];
+          float t = 0.f;
+          (void)tri_test_flat<T>(mk(f.p0[0], f.p0[1], f.p0[2]), mk(f.e1[0], f.e1[1], f.e1[2]),
+                                 mk(f.e2[0], f.e2[1], f.e2[2]), o, d, bt_to, t, fu, fv);
         }
         bool acc = bhit && (!ok || bt_to < t_to);
         ok = ok || acc;
@@ -929,7 +1006,7 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
   size_t soff = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
   lc.substack_off = (int32_t)soff;
-  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)(kSubStack + kRefStack) * threads * sizeof(int) : 0);
+  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)kBvhLdsWords * threads * sizeof(int) : 0);
   return lc;
 }
 

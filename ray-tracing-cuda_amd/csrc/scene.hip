@@ -117,6 +117,7 @@ struct FacePts {
   V3 p[3];
   float uv[6];
   int orig;
+  uint32_t code;
 };
 
 // Padded bounds of faces [first, first+n): no face the binary32 Moller-Trumbore test can accept
@@ -163,10 +164,10 @@ static int split_range(std::vector<FacePts> &fp, int first, int n) {
   return mid;
 }
 
-// 4-wide sub-tree over the faces [first, first+n) of one reference leaf.  Faces are reordered
-// inside the range (each keeps `orig`).  The answer of a leaf query does not depend on visiting
-// order: it is the accepted face with the smallest t, the highest reference index among equal t
-// (bvh.cuh:127-134 scans in order with `t <= t_to`).  Returns the node index; *depth = levels.
+// 4-wide search tree over the faces [first, first+n) of a mesh.  Faces are reordered inside
+// the range (each keeps `orig` and `code`).  Which leaf of the reference's tree a face sits in
+// is carried by the face, not by this tree, so the split is free to follow the geometry.
+// Returns the node index; *depth = levels.
 static int build_subtree(std::vector<SubNode4> &sub, std::vector<FacePts> &fp, int first, int n, int *depth) {
   const int me = (int)sub.size();
   sub.emplace_back();
@@ -217,9 +218,10 @@ static int build_subtree(std::vector<SubNode4> &sub, std::vector<FacePts> &fp, i
 // reference's per-node re-sort of an already sorted sub-range is the identity for
 // a stable sort; one stable sort of the whole range reproduces it.  (thrust::sort
 // does not promise an order for equal keys; this build fixes it as stable.)
-static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<SubNode4> &sub, std::vector<FacePts> &fp,
-                           int first, int n, int leaf_max, int *sub_depth, int level = 0, int *ref_depth = nullptr) {
-  if (ref_depth && level + 1 > *ref_depth) *ref_depth = level + 1;
+// Every face of a leaf is stamped with the leaf's path code (FaceRec::code).
+static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp, int first, int n, int leaf_max,
+                           int level, uint32_t code, int *ref_depth) {
+  if (level > *ref_depth) *ref_depth = level;
   BvhNode nd;
   for (int k = 0; k < 3; k++) nd.mn[k] = INFINITY, nd.mx[k] = -INFINITY;
   for (int i = 0; i < n; i++)  // bvh.cuh:71-82
@@ -234,16 +236,15 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<SubNode4> &s
   int me = (int)nodes.size();
   nodes.push_back(nd);
   if (n <= leaf_max) {
-    // faces of this leaf get their final physical order inside build_subtree
-    int d = 0;
-    nodes[me].left = build_subtree(sub, fp, first, n, &d);
+    nodes[me].left = -1;
     nodes[me].right = -n;
-    *sub_depth = std::max(*sub_depth, d);
+    for (int i = 0; i < n; i++) fp[first + i].code = code;
     return me;
   }
   int mid = (n - 1) / 2;
-  int l = build_bvh_nodes(nodes, sub, fp, first, mid + 1, leaf_max, sub_depth, level + 1, ref_depth);
-  int r = build_bvh_nodes(nodes, sub, fp, first + mid + 1, n - mid - 1, leaf_max, sub_depth, level + 1, ref_depth);
+  const uint32_t bit = level < 32 ? 0x80000000u >> level : 0u;
+  int l = build_bvh_nodes(nodes, fp, first, mid + 1, leaf_max, level + 1, code, ref_depth);
+  int r = build_bvh_nodes(nodes, fp, first + mid + 1, n - mid - 1, leaf_max, level + 1, code | bit, ref_depth);
   nodes[me].left = l;
   nodes[me].right = r;
   return me;
@@ -368,17 +369,14 @@ std::string Scene::flatten() {
         int depth = 0;
         // an empty mesh is a leaf that can never report a hit: it contributes nothing
         int ref_depth = 0;
-        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, local_sub, fp, 0, hb.n, leaf_max, &depth, 0, &ref_depth) : -1;
-        if (ref_depth + 1 > kRefStack) return "mesh tree too deep for the kernel's reference-tree stack";
+        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, fp, 0, hb.n, leaf_max, 0, 0u, &ref_depth) : -1;
+        if (ref_depth > kRefDepthMax) return "mesh tree too deep for the kernel's leaf path codes";
+        br.sub_root = hb.n > 0 ? build_subtree(local_sub, fp, 0, hb.n, &depth) + sub_base : -1;
         sub_depth = std::max(sub_depth, depth);
-        if (3 * depth + 1 > kSubStack) return "mesh leaf too deep for the kernel's sub-tree stack";
+        if (3 * depth + 1 > kSubStack) return "mesh too deep for the kernel's search stack";
         const int node_base = (int)nodes.size();
         for (BvhNode nd : local_nodes) {  // rebase indices into the scene-wide arrays
-          if (nd.right < 0) {
-            nd.left += sub_base;
-          } else {
-            nd.left += node_base, nd.right += node_base;
-          }
+          if (nd.right >= 0) nd.left += node_base, nd.right += node_base;
           nodes.push_back(nd);
         }
         for (SubNode4 nd : local_sub) {
@@ -395,11 +393,12 @@ std::string Scene::flatten() {
         if (br.root >= 0) br.root += node_base;
         if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
         if (has_uv) face_uv.resize((size_t)(face_base + hb.n) * 6, 0.f);
-        for (int i = 0; i < hb.n; i++) {  // physical order = sub-tree order
+        for (int i = 0; i < hb.n; i++) {  // physical order = search-tree order
           TriRec t = make_tri(fp[i].p[0], fp[i].p[1], fp[i].p[2]);
           FaceRec f{};
           for (int c = 0; c < 3; c++) f.p0[c] = t.p0[c], f.e1[c] = t.e1[c], f.e2[c] = t.e2[c];
           f.orig = fp[i].orig;
+          f.code = fp[i].code;
           faces.push_back(f);
           if (has_uv)  // texture coordinates stay in the reference's order, addressed by `orig`
             for (int j = 0; j < 6; j++) face_uv[(size_t)(face_base + fp[i].orig) * 6 + j] = fp[i].uv[j];

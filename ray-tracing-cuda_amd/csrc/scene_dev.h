@@ -73,7 +73,8 @@ struct TexRec {  // 32 B
 
 // The reference's tree (bvh.cuh:113-121): exact bounds, median split of the
 // positions_[0].x-sorted faces, leaves of up to kMin faces; inner: left/right = child node
-// indices; leaf: left = root of the leaf's sub-tree in `subnodes`, right = -(face count).
+// indices; leaf: left = -1, right = -(face count).  The kernel never descends it to find
+// faces; it only replays the box tests on the root-to-leaf paths of the leaves that hold a hit.
 struct BvhNode {  // 32 B
   float mn[3];
   float mx[3];
@@ -81,32 +82,41 @@ struct BvhNode {  // 32 B
   int32_t right;  // negative marks a leaf
 };
 
-// Per-leaf sub-trees: 4-wide nodes with conservative (padded) child bounds, stored child-major
-// per plane so one 128-byte fetch (eight 16-byte loads) serves four slab tests.
-// child[i] >= 0: sub-node index; child[i] < 0: faces, encoded -(first*8 + count) - 1 with
-// count in 1..4; unused slots have an empty box (mn = +inf, mx = -inf) and count 0.
+// The search structure: one 4-wide tree per mesh over ALL its faces, with conservative
+// (padded) child bounds, stored child-major per plane so one 128-byte fetch (eight 16-byte
+// loads) serves four slab tests.  child[i] >= 0: sub-node index; child[i] < 0: faces, encoded
+// -(first*8 + count) - 1 with count in 1..4; unused slots have an empty box (mn = +inf,
+// mx = -inf) and count 0.
 struct alignas(16) SubNode4 {  // 128 B
   float mnx[4], mny[4], mnz[4];
   float mxx[4], mxy[4], mxz[4];
   int32_t child[4];
   int32_t pad[4];
 };
-constexpr int kSubStack = 32;  // per-lane sub-tree stack entries (LDS); 3 * depth + 1 must fit
-constexpr int kRefStack = 24;  // per-lane reference-tree stack entries (LDS); depth + 1 must fit
+constexpr int kSubStack = 32;  // per-lane search stack entries (LDS); 3 * depth + 1 must fit
+constexpr int kHitSlots = 8;   // per-lane candidate list: one (code, face, t) entry per leaf holding a hit
+constexpr int kHitWords = 4;   // words per entry: code, face, t (one or two words)
+constexpr int kBvhLdsWords = kSubStack + kHitSlots * kHitWords;  // LDS words per lane
+constexpr int kRefDepthMax = 32;  // decisions below the root that a leaf's path code can hold
 
 struct BvhRec {  // one per BVH hitable
-  int32_t root;      // node index
+  int32_t root;      // reference-tree node index
   int32_t mat;       // -1: keep "material_ptr_ == nullptr"
   int32_t has_uv;
   int32_t face_base;  // first face of this mesh: face_uv row = face_base + FaceRec::orig
+  int32_t sub_root;   // root of the mesh's 4-wide search tree
+  int32_t pad[3];
 };
 
 struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the winner only
   float p0[3];
   float e1[3];
   float e2[3];
-  int32_t orig;  // index in the reference's (sorted) face order: decides ties, addresses face_uv
-  int32_t pad[2];
+  int32_t orig;   // index in the reference's (sorted) face order: decides ties, addresses face_uv
+  uint32_t code;  // the reference leaf holding the face: its left(0)/right(1) decisions below the
+                  // root, first decision in bit 31, zero-filled.  Leaves are never prefixes of each
+                  // other, so codes identify leaves and increase in the reference's visiting order.
+  int32_t pad;
 };
 
 struct CameraDev {

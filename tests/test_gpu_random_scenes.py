@@ -99,3 +99,64 @@ def test_random_world_bit_exact(seed):
     assert R.total_rays() == o_total
     assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
     assert np.array_equal(img.cpu().numpy(), o_rgb), np.abs(img.cpu().numpy() - o_rgb).max()
+
+
+def _layer_stack(n_layers, rng, jitter):
+    """Quads perpendicular to the x axis, one after another along it: a ray travelling along x
+    finds a hit in every layer, i.e. in far more reference leaves than the kernel's per-lane
+    candidate list has slots."""
+    faces = []
+    for k in range(n_layers):
+        x = -2.0 + 4.0 * k / max(n_layers - 1, 1)
+        dx = rng.uniform(-jitter, jitter, 4)
+        p = [np.array([x + dx[0], -0.6, -2.6]), np.array([x + dx[1], 0.9, -2.6]),
+             np.array([x + dx[2], 0.9, -1.2]), np.array([x + dx[3], -0.6, -1.2])]
+        faces.append([p[0], p[1], p[2]])
+        faces.append([p[0], p[2], p[3]])
+    return np.asarray(faces, dtype=np.float32)
+
+
+@pytest.mark.parametrize("case", [
+    # (layers, leaf size, material, jitter): leaves of 1..3 faces give 2x..0.7x leaves per layer
+    # floor: a sphere selects the double-precision kernel variant, a parallelogram the float one
+    (40, 1, "dielectric", 0.0, "sphere"), (40, 2, "dielectric", 0.02, "pgram"), (25, 3, "dielectric", 0.05, "pgram"),
+    (12, 2, "lambertian", 0.0, "pgram"), (64, 2, "metal", 0.01, "sphere"), (40, 2048, "dielectric", 0.02, "pgram"),
+    (40, 1, "dielectric", 0.0, "pgram"),
+])
+def test_many_hit_leaves_along_one_ray(case):
+    """Mesh rays that hold hits in tens of reference leaves at once (more than kHitSlots):
+    the search defers the leaves beyond its list to further passes; the result must still be
+    the reference's in-order walk, bit for bit."""
+    import torch
+    n_layers, k_min, kind, jitter, floor = case
+    h, w, spp, depth = 24, 40, 3, 30
+    results = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        rng = np.random.default_rng(4242)
+        b = make(5)
+        # the camera looks along +x through the whole stack
+        b.camera_pinhole(v3(-4.5, 0.2, -1.9), v3(0, 0.15, -1.9), v3(0, 1, 0), PI_D / 4, w / h)
+        if kind == "dielectric":
+            m = b.dielectric(v3(0.95, 0.97, 0.99), 1.0)  # index 1: goes straight on, every layer is met
+        elif kind == "metal":
+            m = b.metal(v3(0.9, 0.9, 0.9), 0.3)
+        else:
+            m = b.lambertian(v3(0.7, 0.6, 0.5))
+        b.bvh(_layer_stack(n_layers, rng, jitter), m, k_min=k_min)
+        if floor == "sphere":
+            b.sphere(v3(0, -100.7, -2), 100.0, b.lambertian(v3(0.5, 0.5, 0.5)))
+        else:
+            b.parallelogram([v3(-50, -0.7, -50), v3(50, -0.7, -50), v3(-50, -0.7, 50)], b.lambertian(v3(0.5, 0.5, 0.5)))
+        b.sky()
+        results.append(b)
+    o, p = results
+    o_rgb, o_rays, o_states, o_total = o.render(h, w, spp, depth, post=False)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth, False).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert o_total > h * w * spp * (2 if kind == "dielectric" else 1)  # paths do continue through the stack
+    assert R.total_rays() == o_total
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb), np.abs(img.cpu().numpy() - o_rgb).max()
