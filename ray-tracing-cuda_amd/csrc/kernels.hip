@@ -419,12 +419,27 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           sstack[(stop++) * nthr] = br.sub_root;
           const float lo0 = T_FROM_F * 0.999f, hi0 = (float)bt_to * 1.0001f + 1e-6f;
           while (stop > 0) {
+            // An entry is a 4-wide node (>= 0; 128 B) or a range of up to four faces (< 0;
+            // 4 x 48 B, `faces` carries 4 records of padding).  Lanes of a wave rarely agree on
+            // which, so both kinds are fetched by the same eight 16-byte loads (plus four more
+            // on face lanes) BEFORE the kind is branched on: one memory round trip per step,
+            // not one per side of the branch.
             const int e = sstack[(--stop) * nthr];
-            if (e >= 0) {
-              // one 128-byte node: four padded child boxes (plane-major) + four child references
-              const float4 *np4 = reinterpret_cast<const float4 *>(sc.subnodes + e);
-              const float4 mnx = np4[0], mny = np4[1], mnz = np4[2], mxx = np4[3], mxy = np4[4], mxz = np4[5];
-              const float4 chf = np4[6];
+            const bool is_node = e >= 0;
+            const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
+            const float4 *base = is_node ? reinterpret_cast<const float4 *>(sc.subnodes + e)
+                                         : reinterpret_cast<const float4 *>(sc.faces + first);
+            float4 q[12];
+#pragma unroll
+            for (int w = 0; w < 8; w++) q[w] = base[w];
+            if (!is_node) {
+#pragma unroll
+              for (int w = 8; w < 12; w++) q[w] = base[w];
+            }
+            if (is_node) {
+              // four padded child boxes (plane-major) + four child references
+              const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+              const float4 chf = q[6];
               const float cmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, cmny[4] = {mny.x, mny.y, mny.z, mny.w},
                           cmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, cmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w},
                           cmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, cmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
@@ -439,13 +454,6 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                 if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * nthr] = cch[c];
               }
             } else {
-              // <= 4 faces: all records (3 x 16 B each) are fetched before any test so the
-              // memory round trips overlap; `faces` carries 4 records of padding
-              const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
-              const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + first);
-              float4 q[12];
-#pragma unroll
-              for (int w = 0; w < 12; w++) q[w] = fp4[w];
 #pragma unroll
               for (int fi = 0; fi < 4; fi++) {
                 if (fi < fcnt) {
