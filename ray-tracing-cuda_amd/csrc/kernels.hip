@@ -35,6 +35,8 @@
 #include <stdint.h>
 
 #include "kernels.h"
+
+#include <cstdlib>
 #include "scene_dev.h"
 #include "vec.h"
 #include "xorwow.h"
@@ -258,6 +260,61 @@ __device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V
   return lo <= hi;
 }
 
+
+// ------------------------------------------------------------------ mesh search helpers
+// Per-lane candidate list in LDS, [slot][word][thread]: word 0 = leaf path code, 1 = face
+// index, 2 (and 3 when t is double) = t.  One entry per reference leaf that holds a hit.
+template <typename T, bool DT>
+__device__ __forceinline__ T hit_list_t(const int *hits, int nthr, int slot) {
+  if (DT) return (T)__hiloint2double(hits[(slot * kHitWords + 3) * nthr], hits[(slot * kHitWords + 2) * nthr]);
+  return (T)__int_as_float(hits[(slot * kHitWords + 2) * nthr]);
+}
+// Record a face that passed the triangle test with parameter t.  Same leaf: the smaller t wins,
+// the higher reference index among equal t (what an in-order scan with `t <= t_to` keeps,
+// bvh.cuh:127-134).  A full list keeps the leaves that come first in visiting order and moves
+// `cut` down to the first leaf it had to leave to the next pass.
+template <typename T, bool DT>
+__device__ __forceinline__ void hit_list_insert(const SceneDev &sc, int *hits, int nthr, int &cnt, int64_t lo_code,
+                                                int64_t &cut, uint32_t code, int face, int orig, float t) {
+  if (!((int64_t)code >= lo_code && (int64_t)code < cut)) return;
+  int found = -1, jmax = 0;
+  uint32_t cmax = 0u;
+  for (int j = 0; j < cnt; j++) {
+    const uint32_t cj = (uint32_t)hits[(j * kHitWords + 0) * nthr];
+    if (cj == code) found = j;
+    if (cj >= cmax) cmax = cj, jmax = j;
+  }
+  int slot = -1;
+  if (found >= 0) {
+    const T tj = hit_list_t<T, DT>(hits, nthr, found);
+    bool better = (T)t < tj;
+    if ((T)t == tj) better = orig > sc.faces[hits[(found * kHitWords + 1) * nthr]].orig;
+    if (better) slot = found;
+  } else if (cnt < kHitSlots) {
+    slot = cnt++;
+  } else if (code > cmax) {
+    cut = (int64_t)code;  // this leaf and everything after it: next pass
+  } else {
+    cut = (int64_t)cmax;  // drop the last listed leaf instead
+    slot = jmax;
+  }
+  if (slot >= 0) {
+    hits[(slot * kHitWords + 0) * nthr] = (int)code;
+    hits[(slot * kHitWords + 1) * nthr] = face;
+    if (DT) {
+      const double td = (double)(T)t;
+      hits[(slot * kHitWords + 2) * nthr] = __double2loint(td);
+      hits[(slot * kHitWords + 3) * nthr] = __double2hiint(td);
+    } else {
+      hits[(slot * kHitWords + 2) * nthr] = __float_as_int(t);
+    }
+  }
+}
+__device__ __forceinline__ float lane_bcast(float x, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
+}
+__device__ __forceinline__ int lane_bcast(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
+
 struct Hit {
   bool ok;
   float t;        // float(record.t)
@@ -270,9 +327,12 @@ struct Hit {
 // HitableList::Hit (hitable_list.cu:7-25) over the flattened world.  A nested
 // Parallelepiped list is equivalent to its six parallelograms inlined at its
 // position (DESIGN.md "List flattening").
+// `live`: mesh variants are entered by ALL lanes of the wave (the mesh search borrows idle
+// lanes); a lane that is not tracing passes live = false and gets an unused result.  The other
+// variants are only entered by tracing lanes and pass true.
 template <uint32_t F>
 __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes,
-                                           int *s_substack, V3 o, V3 d) {
+                                           int *s_substack, int coop_lanes, V3 o, V3 d, bool live) {
   constexpr bool DT = (F & F_SPHERE) != 0;
   typedef typename TSel<DT>::type T;
   bool ok = false;
@@ -292,7 +352,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
     const i32x4 rv = load_run(sc.runs, ri);
     Run run;
     run.kind = rv[0], run.first = rv[1], run.count = rv[2], run.pad = 0;
-    if (run.kind == RUN_SKY) {
+    if (live && run.kind == RUN_SKY) {
       // sky.cu:18-27: t = 1e9; t_from <= 1e9 always holds
       const T ts = (T)1e9f;
       bool hit = ts <= t_to;
@@ -301,7 +361,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       t_to = acc ? ts : t_to;
       win = acc ? make_id(RUN_SKY, 0) : win;
     }
-    if ((F & F_TRIS) && run.kind == RUN_TRIS) {
+    if ((F & F_TRIS) && live && run.kind == RUN_TRIS) {
       // Records come in (first, second) pairs: a Parallelogram's two triangles, or a lone
       // Triangle followed by an inert record.  Two SGPR buffers ping-pong: while record A
       // is tested the fetch of B is in flight, and vice versa.  Scalar-memory waits are
@@ -347,7 +407,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         }
       }
     }
-    if ((F & F_SPHERE) && run.kind == RUN_SPHERE) {
+    if ((F & F_SPHERE) && live && run.kind == RUN_SPHERE) {
       f32x8 nxt = load_sphere(sc.spheres, run.first);
       for (int i = 0; i < run.count; i++) {
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the triangle loop
@@ -401,6 +461,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       const int nthr = blockDim.x;
       int *sstack = s_substack + threadIdx.x;                                // [level][thread]
       int *hits = s_substack + (size_t)kSubStack * nthr + threadIdx.x;       // [slot][word][thread]
+      const int lane = (int)(threadIdx.x & 63u), wave_tid0 = (int)(threadIdx.x & ~63u);
+      int *wstack = s_substack + (size_t)kBvhLdsWords * nthr + (size_t)(threadIdx.x >> 6) * kCoopStack;
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
         T bt_to = t_to;
@@ -412,97 +474,140 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         bool have_prev = false;
         uint32_t prev_code = 0u, entered = 0u;
         int64_t lo_code = 0, cut = (int64_t)1 << 32;
-        for (;;) {
+        bool need = live;
+        // All 64 lanes walk this loop together (dead lanes with need == false): the tail of a
+        // search is finished by the whole wave on behalf of the few lanes still at it.
+        while (__ballot(need) != 0ull) {
           // ---- (1) search: best face per leaf with lo_code <= code < cut, t <= bt_to
           int cnt = 0;
           int stop = 0;
-          sstack[(stop++) * nthr] = br.sub_root;
+          if (need) sstack[(stop++) * nthr] = br.sub_root;
           const float lo0 = T_FROM_F * 0.999f, hi0 = (float)bt_to * 1.0001f + 1e-6f;
-          while (stop > 0) {
-            // An entry is a 4-wide node (>= 0; 128 B) or a range of up to four faces (< 0;
-            // 4 x 48 B, `faces` carries 4 records of padding).  Lanes of a wave rarely agree on
-            // which, so both kinds are fetched by the same eight 16-byte loads (plus four more
-            // on face lanes) BEFORE the kind is branched on: one memory round trip per step,
-            // not one per side of the branch.
-            const int e = sstack[(--stop) * nthr];
-            const bool is_node = e >= 0;
-            const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
-            const float4 *base = is_node ? reinterpret_cast<const float4 *>(sc.subnodes + e)
-                                         : reinterpret_cast<const float4 *>(sc.faces + first);
-            float4 q[12];
-#pragma unroll
-            for (int w = 0; w < 8; w++) q[w] = base[w];
-            if (!is_node) {
-#pragma unroll
-              for (int w = 8; w < 12; w++) q[w] = base[w];
-            }
-            if (is_node) {
-              // four padded child boxes (plane-major) + four child references
-              const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-              const float4 chf = q[6];
-              const float cmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, cmny[4] = {mny.x, mny.y, mny.z, mny.w},
-                          cmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, cmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w},
-                          cmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, cmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-              const int cch[4] = {__float_as_int(chf.x), __float_as_int(chf.y), __float_as_int(chf.z),
-                                  __float_as_int(chf.w)};
-#pragma unroll
-              for (int c = 0; c < 4; c++) {
-                BvhNode bx;
-                bx.mn[0] = cmnx[c], bx.mn[1] = cmny[c], bx.mn[2] = cmnz[c];
-                bx.mx[0] = cmxx[c], bx.mx[1] = cmxy[c], bx.mx[2] = cmxz[c];
-                // an unused slot has mn = +inf, mx = -inf and fails the test
-                if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * nthr] = cch[c];
-              }
-            } else {
-#pragma unroll
-              for (int fi = 0; fi < 4; fi++) {
-                if (fi < fcnt) {
-                  const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
-                  float t = 0.f, u = 0.f, v = 0.f;
-                  if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, bt_to, t, u, v)) {
-                    const uint32_t code = (uint32_t)__float_as_int(c.z);
-                    if ((int64_t)code >= lo_code && (int64_t)code < cut) {
-                      int found = -1, jmax = 0;
-                      uint32_t cmax = 0u;
-                      for (int j = 0; j < cnt; j++) {
-                        const uint32_t cj = (uint32_t)hits[(j * kHitWords + 0) * nthr];
-                        if (cj == code) found = j;
-                        if (cj >= cmax) cmax = cj, jmax = j;
-                      }
-                      int slot = -1;
-                      if (found >= 0) {
-                        // same leaf: smaller t wins, the higher reference index among equal t
-                        T tj;
-                        if (DT) {
-                          tj = (T)__hiloint2double(hits[(found * kHitWords + 3) * nthr],
-                                                   hits[(found * kHitWords + 2) * nthr]);
-                        } else {
-                          tj = (T)__int_as_float(hits[(found * kHitWords + 2) * nthr]);
-                        }
-                        bool better = (T)t < tj;
-                        if ((T)t == tj)
-                          better = __float_as_int(c.y) > sc.faces[hits[(found * kHitWords + 1) * nthr]].orig;
-                        if (better) slot = found;
-                      } else if (cnt < kHitSlots) {
-                        slot = cnt++;
-                      } else if (code > cmax) {
-                        cut = (int64_t)code;  // this leaf and everything after it: next pass
-                      } else {
-                        cut = (int64_t)cmax;  // drop the last listed leaf instead
-                        slot = jmax;
-                      }
-                      if (slot >= 0) {
-                        hits[(slot * kHitWords + 0) * nthr] = (int)code;
-                        hits[(slot * kHitWords + 1) * nthr] = first + fi;
-                        if (DT) {
-                          const double td = (double)(T)t;
-                          hits[(slot * kHitWords + 2) * nthr] = __double2loint(td);
-                          hits[(slot * kHitWords + 3) * nthr] = __double2hiint(td);
-                        } else {
-                          hits[(slot * kHitWords + 2) * nthr] = __float_as_int(t);
-                        }
+          for (;;) {
+            const unsigned long long busy = __ballot(stop > 0);
+            if (busy == 0ull) break;
+            if (__popcll(busy) <= coop_lanes) {
+              // ---- wave-cooperative finish.  Few lanes are still searching (typically rays
+              // that graze the surface and touch hundreds of boxes): one at a time, such a
+              // lane's stack moves to a wave-wide stack and every step pops up to 16 entries
+              // -- each entry handled by 4 lanes, one child box or one face per lane.
+              for (unsigned long long m = busy; m != 0ull; m &= m - 1ull) {
+                const int r = __builtin_ctzll(m);
+                const V3 ro = mk(lane_bcast(o.x, r), lane_bcast(o.y, r), lane_bcast(o.z, r));
+                const V3 rd = mk(lane_bcast(d.x, r), lane_bcast(d.y, r), lane_bcast(d.z, r));
+                const V3 rinv = mk(lane_bcast(inv_d.x, r), lane_bcast(inv_d.y, r), lane_bcast(inv_d.z, r));
+                const float rhi0 = lane_bcast(hi0, r);
+                T rt_to;
+                if (DT) {
+                  const double td = (double)bt_to;
+                  rt_to = (T)__hiloint2double(lane_bcast(__double2hiint(td), r), lane_bcast(__double2loint(td), r));
+                } else {
+                  rt_to = (T)lane_bcast((float)bt_to, r);
+                }
+                int size = lane_bcast(stop, r);
+                if (lane < size) wstack[lane] = s_substack[(size_t)lane * nthr + wave_tid0 + r];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const int grp = lane >> 2, sub = lane & 3;
+                while (size > 0) {
+                  // wide steps only while a worst-case push (16 nodes x 4 children) plus the
+                  // depth-first remainder still fits (see kCoopStack)
+                  const int width = (size + 48 + kSubStack <= kCoopStack) ? (size < 16 ? size : 16) : 1;
+                  const bool mine = grp < width;
+                  int e = 0;
+                  if (mine) e = wstack[size - 1 - grp];
+                  size -= width;
+                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  bool push = false, fhit = false;
+                  int child = -1, face = 0, orig = 0;
+                  uint32_t code = 0u;
+                  float ft = 0.f;
+                  if (mine) {
+                    if (e >= 0) {
+                      const float *nb = reinterpret_cast<const float *>(sc.subnodes + e);
+                      BvhNode bx;
+                      bx.mn[0] = nb[sub], bx.mn[1] = nb[4 + sub], bx.mn[2] = nb[8 + sub];
+                      bx.mx[0] = nb[12 + sub], bx.mx[1] = nb[16 + sub], bx.mx[2] = nb[20 + sub];
+                      child = __float_as_int(nb[24 + sub]);
+                      push = child != -1 && slab_touch(bx, 0.f, ro, rinv, lo0, rhi0);
+                    } else {
+                      const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
+                      if (sub < fcnt) {
+                        face = first + sub;
+                        const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + face);
+                        const float4 a = fp4[0], b = fp4[1], c = fp4[2];
+                        float u = 0.f, v = 0.f;
+                        fhit = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), ro, rd, rt_to, ft, u, v);
+                        orig = __float_as_int(c.y);
+                        code = (uint32_t)__float_as_int(c.z);
                       }
                     }
+                  }
+                  const unsigned long long pm = __ballot(push);
+                  if (push) {
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
+                    wstack[size + rank] = child;
+                  }
+                  size += __popcll(pm);
+                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                  __builtin_amdgcn_wave_barrier();
+                  for (unsigned long long hm = __ballot(fhit); hm != 0ull; hm &= hm - 1ull) {
+                    const int l = __builtin_ctzll(hm);
+                    const uint32_t hcode = (uint32_t)lane_bcast((int)code, l);
+                    const int hface = lane_bcast(face, l), horig = lane_bcast(orig, l);
+                    const float ht = lane_bcast(ft, l);
+                    if (lane == r) hit_list_insert<T, DT>(sc, hits, nthr, cnt, lo_code, cut, hcode, hface, horig, ht);
+                  }
+                }
+              }
+              stop = 0;
+              break;
+            }
+            if (stop > 0) {
+              // ---- per-lane step.  An entry is a 4-wide node (>= 0; 128 B) or a range of up
+              // to four faces (< 0; 4 x 48 B, `faces` carries 4 records of padding).  Lanes of a
+              // wave rarely agree on which, so both kinds are fetched by the same eight 16-byte
+              // loads (plus four more on face lanes) BEFORE the kind is branched on: one memory
+              // round trip per step, not one per side of the branch.
+              const int e = sstack[(--stop) * nthr];
+              const bool is_node = e >= 0;
+              const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
+              const float4 *base = is_node ? reinterpret_cast<const float4 *>(sc.subnodes + e)
+                                           : reinterpret_cast<const float4 *>(sc.faces + first);
+              float4 q[12];
+#pragma unroll
+              for (int w = 0; w < 8; w++) q[w] = base[w];
+              if (!is_node) {
+#pragma unroll
+                for (int w = 8; w < 12; w++) q[w] = base[w];
+              }
+              if (is_node) {
+                // four padded child boxes (plane-major) + four child references
+                const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
+                const float4 chf = q[6];
+                const float cmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, cmny[4] = {mny.x, mny.y, mny.z, mny.w},
+                            cmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, cmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w},
+                            cmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, cmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
+                const int cch[4] = {__float_as_int(chf.x), __float_as_int(chf.y), __float_as_int(chf.z),
+                                    __float_as_int(chf.w)};
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                  BvhNode bx;
+                  bx.mn[0] = cmnx[c], bx.mn[1] = cmny[c], bx.mn[2] = cmnz[c];
+                  bx.mx[0] = cmxx[c], bx.mx[1] = cmxy[c], bx.mx[2] = cmxz[c];
+                  // an unused slot has mn = +inf, mx = -inf and fails the test
+                  if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * nthr] = cch[c];
+                }
+              } else {
+#pragma unroll
+                for (int fi = 0; fi < 4; fi++) {
+                  if (fi < fcnt) {
+                    const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
+                    float t = 0.f, u = 0.f, v = 0.f;
+                    if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, bt_to, t, u, v))
+                      hit_list_insert<T, DT>(sc, hits, nthr, cnt, lo_code, cut, (uint32_t)__float_as_int(c.z), first + fi,
+                                             __float_as_int(c.y), t);
                   }
                 }
               }
@@ -564,7 +669,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
               }
             }
           }
-          if (cut >> 32) break;  // nothing was deferred
+          need = need && !(cut >> 32);  // leaves were deferred: search again from `cut` on
           lo_code = cut;
           cut = (int64_t)1 << 32;
         }
@@ -606,7 +711,8 @@ struct LaunchCfg {
   int32_t nodes_off;   // byte offset of the staged reference-tree nodes
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
   int32_t substack_off;  // byte offset of the per-lane sub-tree stacks (BVH variants)
-  int32_t pad[2];
+  int32_t coop_lanes;  // mesh search: the wave finishes together once at most this many lanes still search
+  int32_t pad;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
 };
 
@@ -737,9 +843,12 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     }
     if (!__any(active)) break;
 
+    Hit h = {};
+    if (F & F_BVH)  // every lane goes in: see closest_hit
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, reinterpret_cast<int *>(smem + lc.substack_off), lc.coop_lanes, o, d,
+                         active);
     if (active) {
-      Hit h = closest_hit<F>(sc, s_nodes, (F & F_BVH) ? lc.lds_nodes : 0,
-                             reinterpret_cast<int *>(smem + lc.substack_off), o, d);
+      if (!(F & F_BVH)) h = closest_hit<F>(sc, s_nodes, 0, reinterpret_cast<int *>(smem + lc.substack_off), 0, o, d, true);
       rays++;
 
       V3 result = splat(0.f);
@@ -1004,6 +1113,10 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
   LaunchCfg lc{};
   lc.tile_order = nullptr;
+  {
+    const char *e = getenv("RTMI_COOP_LANES");  // tuning knob
+    lc.coop_lanes = e ? atoi(e) : kCoopLanes;
+  }
   lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
   lc.wide_ids = sc.n_mats > 256 ? 1 : 0;
   size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
@@ -1014,7 +1127,7 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
   size_t soff = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
   lc.substack_off = (int32_t)soff;
-  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)kBvhLdsWords * threads * sizeof(int) : 0);
+  *lds_bytes = soff + ((variant & F_BVH) ? ((size_t)kBvhLdsWords * threads + (size_t)(threads / 64) * kCoopStack) * sizeof(int) : 0);
   return lc;
 }
 
