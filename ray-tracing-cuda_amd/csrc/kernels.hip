@@ -315,6 +315,102 @@ __device__ __forceinline__ float lane_bcast(float x, int lane) {
 }
 __device__ __forceinline__ int lane_bcast(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
 
+
+// Wave-cooperative finish of a mesh search.  `busy` = the lanes whose search stacks are not
+// empty yet ("owners"), at most 64 / LG of them.  The wave splits into groups of LG lanes, one
+// group per owner; the owner's stack moves to the group's segment of a wave-wide LDS stack and
+// every step pops up to LG / 4 entries per group, 4 lanes per entry -- one child box or one
+// face per lane -- so the owner's chain of dependent steps gets shorter (several entries at
+// once) and cheaper (a quarter of the arithmetic per lane).  Hits go to the owner's list.
+template <typename T, bool DT, int LG>
+__device__ __forceinline__ void coop_finish(const SceneDev &sc, unsigned long long busy, const int *s_substack,
+                                            int *wstack, int *hits, int nthr, V3 o, V3 d, V3 inv_d, float lo0, float hi0,
+                                            T bt_to, int stop, int &cnt, int64_t lo_code, int64_t &cut) {
+  constexpr int kGroups = 64 / LG, kEntries = LG / 4, kSegment = kCoopStack / kGroups;
+  // kEntries per step only while the segment is sure to hold what they can push (4 each) plus
+  // the depth-first remainder of one-entry steps (at most kSubStack - 1 above the switch point)
+  constexpr int kWideMax = kSegment - 3 * kEntries - (kSubStack - 1);
+  const int lane = (int)(threadIdx.x & 63u), wave_tid0 = (int)(threadIdx.x & ~63u);
+  const int grp = lane / LG, gl = lane % LG, ent = gl >> 2, sub = gl & 3;
+  int owner = -1;
+  {
+    unsigned long long m = busy;
+#pragma unroll
+    for (int k = 0; k < kGroups; k++) {
+      if (m != 0ull) {
+        if (grp == k) owner = __builtin_ctzll(m);
+        m &= m - 1ull;
+      }
+    }
+  }
+  const int src = owner >= 0 ? owner : lane;
+  const V3 ro = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
+  const V3 rd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
+  const V3 rinv = mk(__shfl(inv_d.x, src), __shfl(inv_d.y, src), __shfl(inv_d.z, src));
+  const float rhi0 = __shfl(hi0, src);
+  T rt_to;
+  if (DT) {
+    rt_to = (T)__shfl((double)bt_to, src);
+  } else {
+    rt_to = (T)__shfl((float)bt_to, src);
+  }
+  int size = __shfl(stop, src);
+  if (owner < 0) size = 0;
+  int *wseg = wstack + grp * kSegment;
+  for (int k = gl; k < size; k += LG) wseg[k] = s_substack[(size_t)k * nthr + wave_tid0 + owner];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  while (__ballot(size > 0) != 0ull) {
+    const int want = (kEntries > 1 && size <= kWideMax) ? kEntries : 1;
+    const int width = size < want ? size : want;
+    const bool mine = ent < width;
+    int e = 0;
+    if (mine) e = wseg[size - 1 - ent];
+    size -= width;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    bool push = false, fhit = false;
+    int child = -1, face = 0, orig = 0;
+    uint32_t code = 0u;
+    float ft = 0.f;
+    if (mine) {
+      if (e >= 0) {
+        const float *nb = reinterpret_cast<const float *>(sc.subnodes + e);
+        BvhNode bx;
+        bx.mn[0] = nb[sub], bx.mn[1] = nb[4 + sub], bx.mn[2] = nb[8 + sub];
+        bx.mx[0] = nb[12 + sub], bx.mx[1] = nb[16 + sub], bx.mx[2] = nb[20 + sub];
+        child = __float_as_int(nb[24 + sub]);
+        push = child != -1 && slab_touch(bx, 0.f, ro, rinv, lo0, rhi0);
+      } else {
+        const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
+        if (sub < fcnt) {
+          face = first + sub;
+          const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + face);
+          const float4 a = fp4[0], b = fp4[1], c = fp4[2];
+          float u = 0.f, v = 0.f;
+          fhit = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), ro, rd, rt_to, ft, u, v);
+          orig = __float_as_int(c.y);
+          code = (uint32_t)__float_as_int(c.z);
+        }
+      }
+    }
+    const unsigned long long pm = __ballot(push);
+    const uint32_t pg = (uint32_t)(pm >> (grp * LG)) & ((1u << LG) - 1u);  // my group's pushes
+    if (push) wseg[size + __popc(pg & ((1u << gl) - 1u))] = child;
+    size += __popc(pg);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned long long hm = __ballot(fhit); hm != 0ull; hm &= hm - 1ull) {
+      const int l = __builtin_ctzll(hm);
+      const int to = lane_bcast(owner, l);
+      const uint32_t hcode = (uint32_t)lane_bcast((int)code, l);
+      const int hface = lane_bcast(face, l), horig = lane_bcast(orig, l);
+      const float ht = lane_bcast(ft, l);
+      if (lane == to) hit_list_insert<T, DT>(sc, hits, nthr, cnt, lo_code, cut, hcode, hface, horig, ht);
+    }
+  }
+}
+
 struct Hit {
   bool ok;
   float t;        // float(record.t)
@@ -461,7 +557,6 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       const int nthr = blockDim.x;
       int *sstack = s_substack + threadIdx.x;                                // [level][thread]
       int *hits = s_substack + (size_t)kSubStack * nthr + threadIdx.x;       // [slot][word][thread]
-      const int lane = (int)(threadIdx.x & 63u), wave_tid0 = (int)(threadIdx.x & ~63u);
       int *wstack = s_substack + (size_t)kBvhLdsWords * nthr + (size_t)(threadIdx.x >> 6) * kCoopStack;
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
@@ -487,80 +582,18 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
             const unsigned long long busy = __ballot(stop > 0);
             if (busy == 0ull) break;
             if (__popcll(busy) <= coop_lanes) {
-              // ---- wave-cooperative finish.  Few lanes are still searching (typically rays
-              // that graze the surface and touch hundreds of boxes): one at a time, such a
-              // lane's stack moves to a wave-wide stack and every step pops up to 16 entries
-              // -- each entry handled by 4 lanes, one child box or one face per lane.
-              for (unsigned long long m = busy; m != 0ull; m &= m - 1ull) {
-                const int r = __builtin_ctzll(m);
-                const V3 ro = mk(lane_bcast(o.x, r), lane_bcast(o.y, r), lane_bcast(o.z, r));
-                const V3 rd = mk(lane_bcast(d.x, r), lane_bcast(d.y, r), lane_bcast(d.z, r));
-                const V3 rinv = mk(lane_bcast(inv_d.x, r), lane_bcast(inv_d.y, r), lane_bcast(inv_d.z, r));
-                const float rhi0 = lane_bcast(hi0, r);
-                T rt_to;
-                if (DT) {
-                  const double td = (double)bt_to;
-                  rt_to = (T)__hiloint2double(lane_bcast(__double2hiint(td), r), lane_bcast(__double2loint(td), r));
-                } else {
-                  rt_to = (T)lane_bcast((float)bt_to, r);
-                }
-                int size = lane_bcast(stop, r);
-                if (lane < size) wstack[lane] = s_substack[(size_t)lane * nthr + wave_tid0 + r];
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                const int grp = lane >> 2, sub = lane & 3;
-                while (size > 0) {
-                  // wide steps only while a worst-case push (16 nodes x 4 children) plus the
-                  // depth-first remainder still fits (see kCoopStack)
-                  const int width = (size + 48 + kSubStack <= kCoopStack) ? (size < 16 ? size : 16) : 1;
-                  const bool mine = grp < width;
-                  int e = 0;
-                  if (mine) e = wstack[size - 1 - grp];
-                  size -= width;
-                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                  __builtin_amdgcn_wave_barrier();
-                  bool push = false, fhit = false;
-                  int child = -1, face = 0, orig = 0;
-                  uint32_t code = 0u;
-                  float ft = 0.f;
-                  if (mine) {
-                    if (e >= 0) {
-                      const float *nb = reinterpret_cast<const float *>(sc.subnodes + e);
-                      BvhNode bx;
-                      bx.mn[0] = nb[sub], bx.mn[1] = nb[4 + sub], bx.mn[2] = nb[8 + sub];
-                      bx.mx[0] = nb[12 + sub], bx.mx[1] = nb[16 + sub], bx.mx[2] = nb[20 + sub];
-                      child = __float_as_int(nb[24 + sub]);
-                      push = child != -1 && slab_touch(bx, 0.f, ro, rinv, lo0, rhi0);
-                    } else {
-                      const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
-                      if (sub < fcnt) {
-                        face = first + sub;
-                        const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + face);
-                        const float4 a = fp4[0], b = fp4[1], c = fp4[2];
-                        float u = 0.f, v = 0.f;
-                        fhit = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), ro, rd, rt_to, ft, u, v);
-                        orig = __float_as_int(c.y);
-                        code = (uint32_t)__float_as_int(c.z);
-                      }
-                    }
-                  }
-                  const unsigned long long pm = __ballot(push);
-                  if (push) {
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0u));
-                    wstack[size + rank] = child;
-                  }
-                  size += __popcll(pm);
-                  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                  __builtin_amdgcn_wave_barrier();
-                  for (unsigned long long hm = __ballot(fhit); hm != 0ull; hm &= hm - 1ull) {
-                    const int l = __builtin_ctzll(hm);
-                    const uint32_t hcode = (uint32_t)lane_bcast((int)code, l);
-                    const int hface = lane_bcast(face, l), horig = lane_bcast(orig, l);
-                    const float ht = lane_bcast(ft, l);
-                    if (lane == r) hit_list_insert<T, DT>(sc, hits, nthr, cnt, lo_code, cut, hcode, hface, horig, ht);
-                  }
-                }
-              }
+              // ---- wave-cooperative finish (see coop_finish): the fewer lanes are left, the
+              // more lanes work for each of them
+              const int left = __popcll(busy);
+              if (left <= 4)
+                coop_finish<T, DT, 16>(sc, busy, s_substack, wstack, hits, nthr, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
+                                       lo_code, cut);
+              else if (left <= 8)
+                coop_finish<T, DT, 8>(sc, busy, s_substack, wstack, hits, nthr, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
+                                      lo_code, cut);
+              else
+                coop_finish<T, DT, 4>(sc, busy, s_substack, wstack, hits, nthr, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
+                                      lo_code, cut);
               stop = 0;
               break;
             }
@@ -1116,6 +1149,8 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   {
     const char *e = getenv("RTMI_COOP_LANES");  // tuning knob
     lc.coop_lanes = e ? atoi(e) : kCoopLanes;
+    if (lc.coop_lanes > kCoopLanes) lc.coop_lanes = kCoopLanes;  // one group of >= 4 lanes per finishing search
+    if (lc.coop_lanes < 0) lc.coop_lanes = 0;
   }
   lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
   lc.wide_ids = sc.n_mats > 256 ? 1 : 0;

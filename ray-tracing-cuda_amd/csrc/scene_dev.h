@@ -97,10 +97,8 @@ constexpr int kSubStack = 32;  // per-lane search stack entries (LDS); 3 * depth
 constexpr int kHitSlots = 8;   // per-lane candidate list: one (code, face, t) entry per leaf holding a hit
 constexpr int kHitWords = 4;   // words per entry: code, face, t (one or two words)
 constexpr int kBvhLdsWords = kSubStack + kHitSlots * kHitWords;  // LDS words per lane
-constexpr int kCoopLanes = 8;    // at most this many lanes still searching: the wave finishes their searches together
-constexpr int kCoopStack = 512;  // per-wave stack of the cooperative search (LDS words).  A 16-entry step
-                                 // pushes at most 64 and is only taken while 48 + kSubStack words stay free;
-                                 // one-entry steps are a depth-first walk whose excess kSubStack bounds
+constexpr int kCoopLanes = 16;   // cooperative finish once at most this many lanes still search (>= 4 lanes each)
+constexpr int kCoopStack = 512;  // per-wave LDS words of the cooperative finish, split evenly between its groups
 constexpr int kRefDepthMax = 32;  // decisions below the root that a leaf's path code can hold
 
 struct BvhRec {  // one per BVH hitable
