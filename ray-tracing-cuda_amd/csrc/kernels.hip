@@ -438,9 +438,11 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   float bu = 0.f, bv = 0.f;
 
   double sa = 0.0, sa2 = 0.0;
+  float saf = 0.f;
   if (F & F_SPHERE) {
     float la = len3(d);       // sphere.cu:13: pow(length(dir), 2) in float, then widened
-    sa = (double)(la * la);
+    saf = la * la;
+    sa = (double)saf;
     sa2 = 2 * sa;
   }
 
@@ -513,7 +515,21 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         __builtin_amdgcn_sched_barrier(0);
         const double r2 = __hiloint2double(__float_as_int(cur[7]), __float_as_int(cur[6]));
         V3 oc = o - mk(cur[0], cur[1], cur[2]);
-        double b = (double)(2.0f * dot3(d, oc));
+        const float bf = 2.0f * dot3(d, oc);
+        {
+          // Wave-level cull.  The reference's discriminant is b*b - 4*a*c in double from the
+          // binary32 values b, a = |d|^2, |oc|^2 (sphere.cu:13-17).  The same expression in
+          // binary32 (with dot(oc,oc) for |oc|^2, i.e. without the square root) is off by at
+          // most a few ulp of its largest term; when it is below -1e-5 of the terms' magnitude
+          // on EVERY lane the exact discriminant is negative on every lane, no lane can hit, and
+          // the binary64 part is skipped.  Lanes of a wave carry unrelated rays, but a small
+          // sphere is in the way of few of them.  (NaN/inf compare false: not skipped.)
+          const float oc2 = dot3(oc, oc), r2f = (float)r2;
+          const float disc_f = bf * bf - 4.0f * saf * (oc2 - r2f);
+          const float mag = bf * bf + 4.0f * saf * (oc2 + r2f);
+          if (!__any(!(disc_f < -1e-5f * mag))) continue;
+        }
+        double b = (double)bf;
         float lc = len3(oc);
         double c = (double)(lc * lc) - r2;
         double disc = b * b - 4 * sa * c;
