@@ -105,3 +105,25 @@ def test_pitched_texture_rows():
     assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
     rel = np.sqrt(((img.cpu().numpy() - o_rgb) ** 2).sum() / (o_rgb ** 2).sum())
     assert rel <= 1e-3
+
+
+@pytest.mark.parametrize("floor", ["sphere", "pgram"])
+def test_mesh_with_more_reference_nodes_than_the_lds_stage_holds(floor):
+    """2,700 faces in leaves of <= 2 give ~2,700 reference-tree nodes: only the first 512 are
+    staged in LDS, the replay of the box tests reads the rest from global memory.  Two meshes in
+    one world, so node / face / search-tree indices of the second are rebased."""
+    from rtmi.scenes import procedural_bunny_mesh
+    mesh = procedural_bunny_mesh(15)  # 12 * 15 * 15 faces around (-0.017, 0.11, 0)
+
+    def fill(b):
+        b.camera_pinhole(v3(0.04, 0.14, -0.45), v3(0.04, 0.1, 0.02), v3(0, 1, 0), PI_D / 5, 1.25)
+        b.bvh(mesh, b.lambertian(v3(0.9, 0.9, 0.9)), k_min=2)
+        shifted = (mesh + np.array([0.12, 0.0, 0.05], dtype=np.float32)).astype(np.float32)
+        b.bvh(shifted, b.metal(v3(0.9, 0.8, 0.7), 0.1), k_min=3)
+        if floor == "sphere":
+            b.sphere(v3(0, -100.0 + 0.03, 0), 100.0, b.lambertian(v3(0.4, 0.6, 0.4)))
+        else:
+            b.parallelogram([v3(-5, 0.03, -5), v3(5, 0.03, -5), v3(-5, 0.03, 5)], b.lambertian(v3(0.4, 0.6, 0.4)))
+        b.sky()
+    rgb, rays = render_both(fill, h=40, w=50, spp=2, depth=12, post=False)
+    assert (rays > 2).mean() > 0.3
