@@ -188,6 +188,14 @@ int rtmi_post_process(float *d_image, int64_t n_pixels, int spp, void *stream);
 /* GetWorkload (utils.cu:111-113). */
 int rtmi_get_workload(int rank, int world_size, int spp);
 
+/* Device self-test of the one arithmetic shortcut that is justified by exhaustion rather than by
+ * argument: the triangle test's `1.0f / det` (utils.cu:59) is computed as hardware reciprocal + one
+ * FMA Newton step when |det| < 2^126.  Runs all 2^32 binary32 inputs on the current device.
+ * mismatches[0] = inputs with 2^-126 <= |x| < 2^126 where the shortcut differs from the IEEE
+ * quotient (must be 0 -- the trace kernels rely on it); mismatches[1] = differing inputs outside
+ * that range, where the kernels divide (informative).  About a second. */
+int rtmi_selftest_reciprocal(unsigned long long mismatches[2]);
+
 /* Kernel launch configuration knobs (0 = library default). */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 /* Work-queue order of rtmi_render: 0 = tiles in image order; 1 (default) = longest-first when it

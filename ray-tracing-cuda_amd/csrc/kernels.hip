@@ -126,13 +126,31 @@ __device__ __forceinline__ uint32_t make_id(int kind, int index) { return ((uint
 #define T_FROM_F 0.001f
 #define DET_EPS_F 1e-7f
 
+// Correctly rounded 1 / x in three instructions for 2^-126 <= |x| < 2^126: the hardware
+// reciprocal (within 1 ulp) and one Newton step on the exact FMA residual.  That the result
+// equals the IEEE quotient 1.0f / x for EVERY such x is not argued but checked: the
+// reciprocal_selftest kernel compares all 2^32 bit patterns on the device it runs on
+// (rtmi_selftest_reciprocal, tests/test_gpu_parity.py).  Outside that range (zero, denormal,
+// huge, inf, NaN) callers use the division.
+#define RCP_RN_LIMIT 0x1p126f
+__device__ __forceinline__ float rcp_rn(float x) {
+  const float r = __builtin_amdgcn_rcpf(x);
+  const float e = __builtin_fmaf(-x, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+
 // utils.cu:49-85 with the ray-independent terms precomputed.
 template <typename T>
 __device__ __forceinline__ bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to, float &t, float &u, float &v) {
   V3 pvec = cross3(d, e2);
   float det = dot3(e1, pvec);
   if (fabsf(det) < DET_EPS_F) return false;
-  float inv = 1.0f / det;
+  float inv;  // 1.0f / det (utils.cu:59)
+  if (fabsf(det) < RCP_RN_LIMIT) {
+    inv = rcp_rn(det);
+  } else {
+    inv = 1.0f / det;
+  }
   V3 tvec = o - p0;
   u = dot3(tvec, pvec) * inv;
   if (u < 0.0f || u > 1.0f) return false;
@@ -153,7 +171,15 @@ __device__ __forceinline__ bool tri_test_flat(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T
   V3 pvec = cross3(d, e2);
   float det = dot3(e1, pvec);
   bool ok = !(fabsf(det) < DET_EPS_F);
-  float inv = 1.0f / det;
+  // 1.0f / det (utils.cu:59).  Lanes with |det| < 1e-7 have ok == false and never look at inv;
+  // for the others rcp_rn is the IEEE quotient unless some |det| >= 2^126 (or NaN), in which
+  // case the whole wave divides.
+  float inv;
+  if (__all(fabsf(det) < RCP_RN_LIMIT)) {
+    inv = rcp_rn(det);
+  } else {
+    inv = 1.0f / det;
+  }
   V3 tvec = o - p0;
   u = dot3(tvec, pvec) * inv;
   ok = ok & !((u < 0.0f) | (u > 1.0f));
@@ -1145,6 +1171,29 @@ hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
                      d_max);
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ self-test
+// Compares rcp_rn(x) with 1.0f / x for all 2^32 bit patterns; counts the inputs inside
+// rcp_rn's stated domain on which they differ (must be 0) and, for information, outside it.
+__global__ __launch_bounds__(256) void reciprocal_selftest(unsigned long long *bad) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  unsigned long long in_domain = 0, outside = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+    const float x = __uint_as_float((uint32_t)i);
+    const float ref = 1.0f / x, got = rcp_rn(x);
+    const bool same = __float_as_uint(ref) == __float_as_uint(got) || (ref != ref && got != got);
+    const bool dom = fabsf(x) >= 0x1p-126f && fabsf(x) < RCP_RN_LIMIT;
+    if (!same) {
+      if (dom) in_domain++; else outside++;
+    }
+  }
+  if (in_domain) atomicAdd(&bad[0], in_domain);
+  if (outside) atomicAdd(&bad[1], outside);
+}
+hipError_t launch_reciprocal_selftest(unsigned long long *d_bad, hipStream_t stream) {
+  hipLaunchKernelGGL(reciprocal_selftest, dim3(4096), dim3(256), 0, stream, d_bad);
   return hipGetLastError();
 }
 

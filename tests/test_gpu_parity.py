@@ -237,3 +237,15 @@ def test_longest_first_schedule_does_not_change_the_frame():
         assert np.array_equal(a[0], other[0]) and np.array_equal(a[1], other[1]) and a[3] == other[3]
     assert np.array_equal(gpu_states_rowmajor(a[2], 96, 128), gpu_states_rowmajor(b[2], 96, 128))
     assert L.rtmi_set_schedule(7) < 0
+
+
+def test_reciprocal_shortcut_is_the_ieee_quotient_on_this_device():
+    """The triangle test's 1.0f / det is computed as v_rcp_f32 + one FMA Newton step for
+    |det| < 2^126 (kernels.hip: rcp_rn).  Its equality with the IEEE quotient is established by
+    exhaustion on the device itself: all 2^32 inputs, zero differences inside the domain."""
+    import ctypes as C
+    import rtmi
+    bad = (C.c_ulonglong * 2)()
+    assert rtmi.lib().rtmi_selftest_reciprocal(bad) == 0
+    assert bad[0] == 0
+    assert bad[1] > 0  # outside the domain (denormals, |x| >= 2^126) the shortcut does differ: the kernels divide there
