@@ -165,10 +165,12 @@ __device__ __forceinline__ bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to
 // triangle with unrelated rays, so some lane nearly always survives each early-out and
 // the exec-mask branches only cost scalar instructions; the boolean results are formed
 // exactly as above (NaNs included), only without control flow.
+// `pvec` = cross(d, e2) is passed in: a parallelogram's second triangle (p1,p2,p3) has the same
+// e2 = p3 - p1 = p2 - p0 as the first whenever the corner arithmetic was exact (TRI_SAME_E2,
+// decided on the host by comparing bit patterns) and then reuses the first one's product.
 template <typename T>
-__device__ __forceinline__ bool tri_test_flat(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to, float &t, float &u,
+__device__ __forceinline__ bool tri_test_flat(V3 p0, V3 e1, V3 e2, V3 pvec, V3 o, V3 d, T t_to, float &t, float &u,
                                               float &v) {
-  V3 pvec = cross3(d, e2);
   float det = dot3(e1, pvec);
   bool ok = !(fabsf(det) < DET_EPS_F);
   // 1.0f / det (utils.cu:59).  Lanes with |det| < 1e-7 have ok == false and never look at inv;
@@ -499,7 +501,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         const f32x16 B = load_hot_tri(base, 2 * i + 1);
         __builtin_amdgcn_sched_barrier(0);
         float t = 0.f, u = 0.f, v = 0.f;
-        const bool hit_a = tri_test_flat<T>(mk(A[0], A[1], A[2]), mk(A[3], A[4], A[5]), mk(A[6], A[7], A[8]), o, d,
+        const V3 pv_a = cross3(d, mk(A[6], A[7], A[8]));
+        const bool hit_a = tri_test_flat<T>(mk(A[0], A[1], A[2]), mk(A[3], A[4], A[5]), mk(A[6], A[7], A[8]), pv_a, o, d,
                                             t_to, t, u, v);
         {
           bool acc = hit_a && (!ok || (T)t < t_to);
@@ -517,8 +520,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         __builtin_amdgcn_sched_barrier(0);
         if (__float_as_int(B[13]) & TRI_SECOND) {  // wave-uniform: a lone Triangle has no second record
           // parallelogram.cu:33: the second triangle is tried only when the first missed
-          bool hit_b = tri_test_flat<T>(mk(B[0], B[1], B[2]), mk(B[3], B[4], B[5]), mk(B[6], B[7], B[8]), o, d, t_to,
-                                        t, u, v);
+          V3 pv_b = pv_a;
+          if (!(__float_as_int(B[13]) & TRI_SAME_E2)) pv_b = cross3(d, mk(B[6], B[7], B[8]));  // wave-uniform
+          bool hit_b = tri_test_flat<T>(mk(B[0], B[1], B[2]), mk(B[3], B[4], B[5]), mk(B[6], B[7], B[8]), pv_b, o, d,
+                                        t_to, t, u, v);
           hit_b = hit_b && !hit_a;
           bool acc = hit_b && (!ok || (T)t < t_to);
           ok = ok || acc;
@@ -752,8 +757,9 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           // barycentrics of the winner (the same binary32 operations as in the search)
           const FaceRec f = sc.faces[bface];
           float t = 0.f;
-          (void)tri_test_flat<T>(mk(f.p0[0], f.p0[1], f.p0[2]), mk(f.e1[0], f.e1[1], f.e1[2]),
-                                 mk(f.e2[0], f.e2[1], f.e2[2]), o, d, bt_to, t, fu, fv);
+          const V3 fe2 = mk(f.e2[0], f.e2[1], f.e2[2]);
+          (void)tri_test_flat<T>(mk(f.p0[0], f.p0[1], f.p0[2]), mk(f.e1[0], f.e1[1], f.e1[2]), fe2, cross3(d, fe2), o, d,
+                                 bt_to, t, fu, fv);
         }
         bool acc = bhit && (!ok || bt_to < t_to);
         ok = ok || acc;

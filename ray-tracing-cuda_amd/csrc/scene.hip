@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace rtmi {
@@ -33,8 +34,11 @@ static HotTri hot_tri(V3 p0, V3 p1, V3 p2, int mat, int flags) {
 // parallelogram.cu:10-15 + the two triangles of parallelogram.cu:25,33
 static void push_pgram(std::vector<HotTri> &out, V3 p0, V3 p1, V3 p2, int mat) {
   V3 p3 = p1 + p2 - p0;
-  out.push_back(hot_tri(p0, p1, p2, mat, TRI_PGRAM));
-  out.push_back(hot_tri(p1, p2, p3, mat, TRI_PGRAM | TRI_SECOND));
+  const HotTri first = hot_tri(p0, p1, p2, mat, TRI_PGRAM);
+  HotTri second = hot_tri(p1, p2, p3, mat, TRI_PGRAM | TRI_SECOND);
+  if (memcmp(first.e2, second.e2, sizeof(first.e2)) == 0) second.flags |= TRI_SAME_E2;  // p3 - p1 == p2 - p0 exactly
+  out.push_back(first);
+  out.push_back(second);
 }
 
 // parallelepiped.cu:8-18: derive the four opposite corners.

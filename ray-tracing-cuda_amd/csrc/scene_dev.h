@@ -43,7 +43,8 @@ struct TriRec {  // 48 B: Moller-Trumbore operands that do not depend on the ray
 // One triangle of the world list, 64 B = one s_load_dwordx16.  A Parallelogram is two
 // consecutive records, (p0,p1,p2) then (p1,p2,p3) with TRI_SECOND set: the second is
 // tested only by lanes whose first test missed (parallelogram.cu:25,33).
-enum : int32_t { TRI_SECOND = 1, TRI_PGRAM = 2 };
+// TRI_SAME_E2 (second records only): e2 has the bit pattern of the first record's e2.
+enum : int32_t { TRI_SECOND = 1, TRI_PGRAM = 2, TRI_SAME_E2 = 4 };
 struct HotTri {
   float p0[3];
   float e1[3];
