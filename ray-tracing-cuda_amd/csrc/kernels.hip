@@ -19,9 +19,16 @@
 //     stack of scattered-material ids that the back-to-front radiance fold of
 //     ray_tracing.cu:50-52 needs (one byte per bounce instead of a 12-byte
 //     attenuation in scratch memory);
+//   * mesh (BVH) queries do not walk the reference's tree: one search of a mesh-wide
+//     4-wide tree finds the best face of every reference leaf that holds a hit, then the
+//     reference's box tests are replayed on those leaves' root-to-leaf paths only
+//     (closest_hit, RUN_BVH); the last few searches of a wave are finished by all 64
+//     lanes together (coop_finish);
 //   * arithmetic follows the reference operation by operation (binary32 with
 //     the binary64 islands of sphere.cu / ray_tracing.cu:68-73); the file is
-//     compiled with -ffp-contract=off and IEEE divide/sqrt.
+//     compiled with -ffp-contract=off and IEEE divide/sqrt.  The one shortened
+//     operation, 1.0f / det, is checked against the IEEE quotient on all 2^32 inputs
+//     by reciprocal_selftest.
 //
 // Reference functions restated here (paths relative to
 // /root/reference/ray-tracing-cuda/): PathTracing + Trace ray_tracing.cu:12-85,
