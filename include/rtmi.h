@@ -188,13 +188,17 @@ int rtmi_post_process(float *d_image, int64_t n_pixels, int spp, void *stream);
 /* GetWorkload (utils.cu:111-113). */
 int rtmi_get_workload(int rank, int world_size, int spp);
 
-/* Device self-test of the one arithmetic shortcut that is justified by exhaustion rather than by
- * argument: the triangle test's `1.0f / det` (utils.cu:59) is computed as hardware reciprocal + one
- * FMA Newton step when |det| < 2^126.  Runs all 2^32 binary32 inputs on the current device.
- * mismatches[0] = inputs with 2^-126 <= |x| < 2^126 where the shortcut differs from the IEEE
- * quotient (must be 0 -- the trace kernels rely on it); mismatches[1] = differing inputs outside
- * that range, where the kernels divide (informative).  About a second. */
-int rtmi_selftest_reciprocal(unsigned long long mismatches[2]);
+/* Device self-test of the arithmetic shortcuts that are justified by exhaustion rather than by
+ * argument alone; each is run against the expression it replaces on all 2^32 inputs, on the
+ * current device (about a second):
+ *  [0] the triangle test's `1.0f / det` (utils.cu:59) computed as hardware reciprocal + one FMA
+ *      Newton step when |det| < 2^126: inputs with 2^-126 <= |x| < 2^126 where it differs from the
+ *      IEEE quotient -- must be 0, the trace kernels rely on it;
+ *  [1] differing inputs outside that range, where the kernels divide (informative, > 0);
+ *  [2] CudaRandomFloat(-1, 1) (utils.cuh:22-27) as fma(x, 2^-31, 2^-32) - 1: draws x that differ
+ *      from curand_uniform(x) * (1 - -1) + -1 -- must be 0;
+ *  [3] CudaRandomFloat(0, 1) as fma(x, 2^-32, 2^-33) -- must be 0. */
+int rtmi_selftest_arithmetic(unsigned long long mismatches[4]);
 
 /* Kernel launch configuration knobs (0 = library default). */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);

@@ -540,14 +540,14 @@ int rtmi_post_process(float *d_image, int64_t n_pixels, int spp, void *stream) {
 int rtmi_get_workload(int rank, int world_size, int spp) {
   return spp / world_size + (int)(rank < (spp % world_size));  // utils.cu:111-113
 }
-int rtmi_selftest_reciprocal(unsigned long long *mismatches) {
+int rtmi_selftest_arithmetic(unsigned long long *mismatches) {
   if (!mismatches) return fail(RTMI_ERR_INVALID, "mismatches == NULL");
   if (rtmi_device_count() <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device: librtmi has no CPU fallback");
   unsigned long long *d_bad = nullptr;
-  HIP_TRY(hipMalloc(&d_bad, 2 * sizeof(unsigned long long)));
-  hipError_t e = hipMemset(d_bad, 0, 2 * sizeof(unsigned long long));
-  if (e == hipSuccess) e = launch_reciprocal_selftest(d_bad, nullptr);
-  if (e == hipSuccess) e = hipMemcpy(mismatches, d_bad, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  HIP_TRY(hipMalloc(&d_bad, 4 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d_bad, 0, 4 * sizeof(unsigned long long));
+  if (e == hipSuccess) e = launch_arithmetic_selftest(d_bad, nullptr);
+  if (e == hipSuccess) e = hipMemcpy(mismatches, d_bad, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d_bad);
   HIP_TRY(e);
   return RTMI_OK;

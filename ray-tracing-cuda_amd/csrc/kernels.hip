@@ -28,7 +28,7 @@
 //     the binary64 islands of sphere.cu / ray_tracing.cu:68-73); the file is
 //     compiled with -ffp-contract=off and IEEE divide/sqrt.  The one shortened
 //     operation, 1.0f / det, is checked against the IEEE quotient on all 2^32 inputs
-//     by reciprocal_selftest.
+//     by arithmetic_selftest (as are the two fused uniform-variate conversions).
 //
 // Reference functions restated here (paths relative to
 // /root/reference/ray-tracing-cuda/): PathTracing + Trace ray_tracing.cu:12-85,
@@ -136,8 +136,8 @@ __device__ __forceinline__ uint32_t make_id(int kind, int index) { return ((uint
 // Correctly rounded 1 / x in three instructions for 2^-126 <= |x| < 2^126: the hardware
 // reciprocal (within 1 ulp) and one Newton step on the exact FMA residual.  That the result
 // equals the IEEE quotient 1.0f / x for EVERY such x is not argued but checked: the
-// reciprocal_selftest kernel compares all 2^32 bit patterns on the device it runs on
-// (rtmi_selftest_reciprocal, tests/test_gpu_parity.py).  Outside that range (zero, denormal,
+// arithmetic_selftest kernel compares all 2^32 bit patterns on the device it runs on
+// (rtmi_selftest_arithmetic, tests/test_gpu_parity.py).  Outside that range (zero, denormal,
 // huge, inf, NaN) callers use the division.
 #define RCP_RN_LIMIT 0x1p126f
 __device__ __forceinline__ float rcp_rn(float x) {
@@ -263,12 +263,21 @@ __device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) {
 // sqrtf(1 + 2^-22) to 1 + 2^-23, so sqrtf(s) > 1  <=>  s > 1 + 2^-23
 // (tests/test_host_logic.py::test_rejection_threshold).  Returns the accepted sum.
 #define BALL_S_MAX 1.00000011920928955078125f /* 1 + 2^-23 */
+// CudaRandomFloat(-1, 1) and (0, 1) (utils.cuh:22-27 over curand_uniform) in fewer instructions.
+// (float)x * 2^-32 is exact, so curand_uniform's u = x * 2^-32 + 2^-33 is one fused
+// multiply-add; u * (1 - (-1)) is an exact doubling that commutes with the rounding of u, so
+// u * 2 + (-1) = fma(x, 2^-31, 2^-32) - 1; and u * (1 - 0) + 0 = u.  Both are also compared with
+// rng_range() on all 2^32 draws by arithmetic_selftest.
+__device__ __forceinline__ float rng_pm1_of(uint32_t x) { return __builtin_fmaf((float)x, 0x1p-31f, 0x1p-32f) - 1.0f; }
+__device__ __forceinline__ float rng_01_of(uint32_t x) { return __builtin_fmaf((float)x, 0x1p-32f, 0x1p-33f); }
+__device__ __forceinline__ float rng_pm1(Rng &s) { return rng_pm1_of(rng_next(s)); }
+__device__ __forceinline__ float rng_01(Rng &s) { return rng_01_of(rng_next(s)); }
 __device__ __forceinline__ V3 ball_sample(Rng &rng, float &sum) {
   float x, y, z;
   do {
-    x = rng_range(-1.f, 1.f, rng);
-    y = rng_range(-1.f, 1.f, rng);
-    z = rng_range(-1.f, 1.f, rng);
+    x = rng_pm1(rng);
+    y = rng_pm1(rng);
+    z = rng_pm1(rng);
     sum = x * x + y * y + z * z;
   } while (sum > BALL_S_MAX);
   return mk(x, y, z);
@@ -811,8 +820,12 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                                             unsigned long long *__restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
-  uint8_t *stack8 = smem + lc.stack_off;
-  uint16_t *stack16 = reinterpret_cast<uint16_t *>(smem + lc.stack_off);
+  // id stack: byte offset of entry [level][thread] in LDS, kept as 32-bit arithmetic (pointer
+  // arithmetic on the generic pointers costs a register pair per live address)
+  const uint32_t ids_shift = lc.wide_ids ? 1u : 0u;
+  auto ids_offset = [&](int level) -> uint32_t {
+    return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << ids_shift);
+  };
   const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
   const bool mats_in_lds = lc.lds_mats > 0;
   if (mats_in_lds) {
@@ -828,7 +841,6 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   __syncthreads();
 
   const int64_t n_items = fr.items;
-  const int tid = threadIdx.x, nthr = blockDim.x;
   const bool w_pow2 = (fr.width & (fr.width - 1)) == 0, h_pow2 = (fr.height & (fr.height - 1)) == 0;
   const double inv_w = 1.0 / (double)fr.width, inv_h = 1.0 / (double)fr.height;
   // per-lane pixel state
@@ -902,8 +914,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       }
       if (has_px) {
         // ray_tracing.cu:68-74 + camera.cu:57-70
-        float r1 = rng_range(0.f, 1.f, rng);
-        float r2 = rng_range(0.f, 1.f, rng);
+        float r1 = rng_01(rng);
+        float r2 = rng_01(rng);
         // division by a power of two is an exact scaling: multiply by the (exact) reciprocal
         double x = (double)r1 + (double)pj;
         double y = (double)r2 + (double)(fr.height - pi);
@@ -1052,9 +1064,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                 att[depth * 3 + 1] = rgb.y;
                 att[depth * 3 + 2] = rgb.z;
               } else if (lc.wide_ids) {
-                stack16[depth * nthr + tid] = (uint16_t)mat;
+                *reinterpret_cast<uint16_t *>(smem + ids_offset(depth)) = (uint16_t)mat;
               } else {
-                stack8[depth * nthr + tid] = (uint8_t)mat;
+                smem[ids_offset(depth)] = (uint8_t)mat;
               }
               depth++;
               o = p;
@@ -1071,7 +1083,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           if (F & F_TEX) {
             a = mk(att[i * 3 + 0], att[i * 3 + 1], att[i * 3 + 2]);
           } else {
-            const int mi = lc.wide_ids ? (int)stack16[i * nthr + tid] : (int)stack8[i * nthr + tid];
+            const int mi = lc.wide_ids ? (int)*reinterpret_cast<const uint16_t *>(smem + ids_offset(i)) : (int)smem[ids_offset(i)];
             if (mats_in_lds) {
               a = mk(s_mats[mi].r, s_mats[mi].g, s_mats[mi].b);
             } else {
@@ -1093,15 +1105,19 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 
 // The trace kernel proper, and the same code under a second name for the scheduler's 2-spp
 // cost probe (so per-kernel profiles keep the two apart).
+// Second launch bound = waves per SIMD the register allocation must allow: the list-only variants
+// sit at the 80-VGPR / 6-wave step and are issue-bound (one wave less costs 5 %), so the step is
+// held explicitly instead of being left to the allocator's luck.
+#define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : 6)
 template <uint32_t F>
-__global__ __launch_bounds__(256) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+__global__ __launch_bounds__(256, RTMI_MIN_WAVES(F)) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
                                                       uint32_t *__restrict__ states, float *__restrict__ out,
                                                       uint32_t *__restrict__ ray_counts,
                                                       unsigned long long *__restrict__ counters) {
   render_body<F>(sc, fr, lc, states, out, ray_counts, counters);
 }
 template <uint32_t F>
-__global__ __launch_bounds__(256) void probe_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+__global__ __launch_bounds__(256, RTMI_MIN_WAVES(F)) void probe_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
                                                      uint32_t *__restrict__ states, float *__restrict__ out,
                                                      uint32_t *__restrict__ ray_counts,
                                                      unsigned long long *__restrict__ counters) {
@@ -1188,25 +1204,37 @@ hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t
 }
 
 // ------------------------------------------------------------------ self-test
-// Compares rcp_rn(x) with 1.0f / x for all 2^32 bit patterns; counts the inputs inside
-// rcp_rn's stated domain on which they differ (must be 0) and, for information, outside it.
-__global__ __launch_bounds__(256) void reciprocal_selftest(unsigned long long *bad) {
+// Runs every shortened operation against the expression it replaces on all 2^32 inputs:
+// bad[0] rcp_rn(x) vs 1.0f / x inside rcp_rn's domain (must be 0), bad[1] outside it
+// (informative), bad[2] rng_pm1_of(x) vs the reference's uniform(-1, 1) expression, bad[3]
+// rng_01_of(x) vs uniform(0, 1) (both must be 0).
+__device__ __forceinline__ float ref_uniform(uint32_t x) { return (float)x * 2.3283064e-10f + 1.16415322e-10f; }
+__device__ __forceinline__ float ref_range(float mn, float mx, uint32_t x) { return ref_uniform(x) * (mx - mn) + mn; }
+__global__ __launch_bounds__(256) void arithmetic_selftest(unsigned long long *bad, float mn1, float mx1, float mn0,
+                                                           float mx0) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  unsigned long long in_domain = 0, outside = 0;
+  unsigned long long in_domain = 0, outside = 0, pm1 = 0, u01 = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
-    const float x = __uint_as_float((uint32_t)i);
+    const uint32_t bits = (uint32_t)i;
+    const float x = __uint_as_float(bits);
     const float ref = 1.0f / x, got = rcp_rn(x);
     const bool same = __float_as_uint(ref) == __float_as_uint(got) || (ref != ref && got != got);
     const bool dom = fabsf(x) >= 0x1p-126f && fabsf(x) < RCP_RN_LIMIT;
     if (!same) {
       if (dom) in_domain++; else outside++;
     }
+    // the range bounds arrive as kernel arguments so that the reference expression is
+    // evaluated operation by operation, not folded at compile time
+    if (__float_as_uint(ref_range(mn1, mx1, bits)) != __float_as_uint(rng_pm1_of(bits))) pm1++;
+    if (__float_as_uint(ref_range(mn0, mx0, bits)) != __float_as_uint(rng_01_of(bits))) u01++;
   }
   if (in_domain) atomicAdd(&bad[0], in_domain);
   if (outside) atomicAdd(&bad[1], outside);
+  if (pm1) atomicAdd(&bad[2], pm1);
+  if (u01) atomicAdd(&bad[3], u01);
 }
-hipError_t launch_reciprocal_selftest(unsigned long long *d_bad, hipStream_t stream) {
-  hipLaunchKernelGGL(reciprocal_selftest, dim3(4096), dim3(256), 0, stream, d_bad);
+hipError_t launch_arithmetic_selftest(unsigned long long *d_bad, hipStream_t stream) {
+  hipLaunchKernelGGL(arithmetic_selftest, dim3(4096), dim3(256), 0, stream, d_bad, -1.f, 1.f, 0.f, 1.f);
   return hipGetLastError();
 }
 

@@ -82,7 +82,7 @@ SYMBOLS = [
     ("rtmi_untile_u32", C.c_int, [_frp, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_post_process", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
     ("rtmi_get_workload", C.c_int, [C.c_int, C.c_int, C.c_int]),
-    ("rtmi_selftest_reciprocal", C.c_int, [C.POINTER(C.c_ulonglong)]),
+    ("rtmi_selftest_arithmetic", C.c_int, [C.POINTER(C.c_ulonglong)]),
     ("rtmi_set_launch", C.c_int, [C.c_int, C.c_int]),
     ("rtmi_set_schedule", C.c_int, [C.c_int]),
 ]

@@ -239,13 +239,14 @@ def test_longest_first_schedule_does_not_change_the_frame():
     assert L.rtmi_set_schedule(7) < 0
 
 
-def test_reciprocal_shortcut_is_the_ieee_quotient_on_this_device():
-    """The triangle test's 1.0f / det is computed as v_rcp_f32 + one FMA Newton step for
-    |det| < 2^126 (kernels.hip: rcp_rn).  Its equality with the IEEE quotient is established by
-    exhaustion on the device itself: all 2^32 inputs, zero differences inside the domain."""
+def test_shortened_arithmetic_equals_the_reference_expressions_on_this_device():
+    """Three operations of the trace loop are computed in fewer instructions than the reference's
+    expression (kernels.hip: rcp_rn for 1.0f / det, rng_pm1_of / rng_01_of for the uniform
+    variates).  Their equality is established by exhaustion on the device itself: all 2^32 inputs
+    each, zero differences (for the reciprocal: inside its stated domain)."""
     import ctypes as C
     import rtmi
-    bad = (C.c_ulonglong * 2)()
-    assert rtmi.lib().rtmi_selftest_reciprocal(bad) == 0
-    assert bad[0] == 0
-    assert bad[1] > 0  # outside the domain (denormals, |x| >= 2^126) the shortcut does differ: the kernels divide there
+    bad = (C.c_ulonglong * 4)()
+    assert rtmi.lib().rtmi_selftest_arithmetic(bad) == 0
+    assert bad[0] == 0 and bad[2] == 0 and bad[3] == 0, list(bad)
+    assert bad[1] > 0  # outside the domain (denormals, |x| >= 2^126) the reciprocal does differ: the kernels divide there
