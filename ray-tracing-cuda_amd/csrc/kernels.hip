@@ -146,6 +146,20 @@ __device__ __forceinline__ float rcp_rn(float x) {
   return __builtin_fmaf(e, r, r);
 }
 
+// glm::normalize = v * (1 / sqrt(v.v)) (vec.h: unit3) with the reciprocal taken by rcp_rn: a
+// positive normal square root always lies inside rcp_rn's domain (2^-75 < sqrt(x) < 2^64); a
+// zero, NaN or infinite one sends the whole wave through the division.
+__device__ __forceinline__ V3 unit3_rn(V3 v) {
+  const float s = sqrtf(dot3(v, v));
+  float inv;
+  if (__all(__builtin_amdgcn_class(s, 0x100))) {  // +normal
+    inv = rcp_rn(s);
+  } else {
+    inv = 1.0f / s;
+  }
+  return v * inv;
+}
+
 // utils.cu:49-85 with the ray-independent terms precomputed.
 template <typename T>
 __device__ __forceinline__ bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to, float &t, float &u, float &v) {
@@ -935,7 +949,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           }
         }
         o = origin;
-        d = unit3(unit3(target - origin));  // RayAt normalises, Ray's constructor normalises again
+        d = unit3_rn(unit3_rn(target - origin));  // RayAt normalises, Ray's constructor normalises again
         k++;
         depth = 0;
         active = true;
@@ -959,7 +973,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         V3 p = o + h.t * d;  // ray_tracing.cu:32 and the materials' own `p`
         if (kind == RUN_SKY) {
           // sky.cu:9-14: Scatter false; Emit(p) = gradient on normalize(p)
-          V3 dir = unit3(p);
+          V3 dir = unit3_rn(p);
           float tg = (float)(0.5 * ((double)dir.y + 1.0));
           float w0 = 1.0f - tg;
           result = mk(w0 * 1.0f + tg * 0.5f, w0 * 1.0f + tg * 0.7f, w0 * 1.0f + tg * 1.0f);
@@ -990,7 +1004,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           }
           if ((F & F_SPHERE) && kind == RUN_SPHERE) {
             const SphereRec &sr = sc.spheres[index];
-            nrm = unit3(p - mk(sr.cx, sr.cy, sr.cz));  // sphere.cu:25-26
+            nrm = unit3_rn(p - mk(sr.cx, sr.cy, sr.cz));  // sphere.cu:25-26
             mat = sr.mat;
             if (F & F_TEX) {  // sphere.cu:60-63
               const float pi_f = 3.14159265358979323846264338327950288f;
@@ -1003,7 +1017,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           if ((F & F_BVH) && kind == RUN_BVH) {
             const FaceRec &fc = sc.faces[index];
             // utils.cu:79: normalize(cross(v0v1, v0v2)), recomputed for the winning face only
-            V3 n = unit3(cross3(mk(fc.e1[0], fc.e1[1], fc.e1[2]), mk(fc.e2[0], fc.e2[1], fc.e2[2])));
+            V3 n = unit3_rn(cross3(mk(fc.e1[0], fc.e1[1], fc.e1[2]), mk(fc.e2[0], fc.e2[1], fc.e2[2])));
             nrm = dot3(d, n) < 0.f ? n : -n;
             const BvhRec br = sc.bvhs[h.aux];
             mat = br.mat;
@@ -1034,7 +1048,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                 V3 s = ball_sample(rng, sum);
                 const float l = sqrtf(sum);
                 s = mk(s.x / l, s.y / l, s.z / l);
-                nd = unit3(s + nrm);
+                nd = unit3_rn(s + nrm);
                 scattered = true;
               }
             } else if (m.kind == MAT_METAL) {  // metal.cu:12-25
@@ -1070,7 +1084,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               }
               depth++;
               o = p;
-              d = unit3(nd);  // Ray's constructor
+              d = unit3_rn(nd);  // Ray's constructor
               ended = false;
             }
           }
