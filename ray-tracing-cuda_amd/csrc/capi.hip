@@ -327,6 +327,15 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.n_runs = (int)s->runs.size();
   d.n_mats = (int)s->mat_recs.size();
   d.n_nodes = (int)s->nodes.size();
+  d.unsigned_colours = 1;
+  for (const MatRec &m : s->mat_recs) {
+    const float c[3] = {m.r, m.g, m.b};
+    for (float x : c) {
+      uint32_t bits;
+      memcpy(&bits, &x, sizeof(bits));
+      if (bits >> 31) d.unsigned_colours = 0;
+    }
+  }
   d.cam = s->cam;
   s->dev = d;
   void *c = nullptr;

@@ -842,6 +842,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   };
   const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
   const bool mats_in_lds = lc.lds_mats > 0;
+  const bool fast_fold = mats_in_lds && !lc.wide_ids && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_mats);
@@ -1091,8 +1092,30 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         }
       }
       if (ended) {
-        // ray_tracing.cu:50-52 with emitted == 0 on every stored layer
-        for (int i = depth - 1; i >= 0; i--) {
+        // ray_tracing.cu:50-52 with emitted == 0 on every stored layer: result = emitted +
+        // attenuation * result, deepest layer first.  The addition only matters for a product of -0,
+        // which needs a colour with its sign bit set (sc.unsigned_colours).
+        int i = depth - 1;
+        if (!(F & F_TEX) && fast_fold) {
+          // common case (byte ids, material table in LDS, no signed colours) without the per-layer
+          // uniform branches: four layers at a time, ids first, then colours, then the products
+          const uint32_t step = blockDim.x;
+          for (; i >= 3; i -= 4) {
+            const uint32_t at = ids_offset(i);
+            const int m0 = smem[at], m1 = smem[at - step], m2 = smem[at - 2u * step], m3 = smem[at - 3u * step];
+            const V3 a0 = mk(s_mats[m0].r, s_mats[m0].g, s_mats[m0].b), a1 = mk(s_mats[m1].r, s_mats[m1].g, s_mats[m1].b);
+            const V3 a2 = mk(s_mats[m2].r, s_mats[m2].g, s_mats[m2].b), a3 = mk(s_mats[m3].r, s_mats[m3].g, s_mats[m3].b);
+            result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
+            result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
+            result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
+            result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
+          }
+          for (; i >= 0; i--) {
+            const int m0 = smem[ids_offset(i)];
+            result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+          }
+        }
+        for (; i >= 0; i--) {
           V3 a;
           if (F & F_TEX) {
             a = mk(att[i * 3 + 0], att[i * 3 + 1], att[i * 3 + 2]);
@@ -1104,7 +1127,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               a = mk(sc.mats[mi].r, sc.mats[mi].g, sc.mats[mi].b);
             }
           }
-          result = mk(0.f + a.x * result.x, 0.f + a.y * result.y, 0.f + a.z * result.z);
+          if (sc.unsigned_colours) {
+            result = mk(a.x * result.x, a.y * result.y, a.z * result.z);
+          } else {
+            result = mk(0.f + a.x * result.x, 0.f + a.y * result.y, 0.f + a.z * result.z);
+          }
         }
         color = color + result;
         active = false;

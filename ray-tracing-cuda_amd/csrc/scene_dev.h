@@ -142,7 +142,9 @@ struct SceneDev {
   const float *face_uv;  // 6 floats per face or nullptr
   const MatRec *mats;
   const TexRec *texs;
-  int32_t n_runs, n_mats, n_nodes, pad0;
+  int32_t n_runs, n_mats, n_nodes;
+  int32_t unsigned_colours;  // 1: no material colour has its sign bit set (not even -0): then every layer
+                             // product is +0, positive or NaN and `emitted(0) + product` is the product itself
   CameraDev cam;
 };
 

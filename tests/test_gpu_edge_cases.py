@@ -127,3 +127,17 @@ def test_mesh_with_more_reference_nodes_than_the_lds_stage_holds(floor):
         b.sky()
     rgb, rays = render_both(fill, h=40, w=50, spp=2, depth=12, post=False)
     assert (rays > 2).mean() > 0.3
+
+
+def test_colours_with_a_sign_bit_keep_the_emitted_plus_product_addition():
+    """ray_tracing.cu:51 folds `emitted + attenuation * result` with emitted == 0 for everything
+    that scatters; the kernel drops the addition unless some material colour has its sign bit set,
+    because only a product of -0 notices it (0 + -0 = +0).  Here colours are negative and -0."""
+    def fill(b):
+        b.sphere(v3(0, -100.5, 0), 100.0, b.lambertian(v3(-0.0, 0.6, 0.5)))
+        b.sphere(v3(-0.6, 0.3, 0), 0.5, b.lambertian(v3(0.8, -0.25, 0.3)))
+        b.sphere(v3(0.6, 0.3, 0), 0.5, b.metal(v3(-0.0, -0.0, 0.9), 0.2))
+        b.parallelogram([v3(-1, 2, -1), v3(1, 2, -1), v3(-1, 2, 1)], b.diffuse_light(b.constant_texture(v3(3, -0.0, 2))))
+        b.sky()
+    rgb, rays = render_both(fill, h=32, w=40, spp=4, depth=12, post=False)
+    assert np.signbit(rgb).any() or (rgb < 0).any()
