@@ -484,7 +484,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   hipStream_t st = (hipStream_t)stream;
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
-  const uint32_t *d_order = nullptr;
+  const uint32_t *d_order = nullptr, *d_sparse = nullptr;
   const int probe_spp = 2;
   const bool many_tiles = (int64_t)d.local_tiles * 64 > (int64_t)blocks * threads;
   if (g_schedule == 2 || (g_schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
@@ -507,14 +507,16 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     probe.spp = probe_spp;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), st));
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
-    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, true, blocks,
-                          threads, st));
-    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, st));
+    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, nullptr, true,
+                          blocks, threads, st));
+    const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / kSparseStride) / 64 * 64);
+    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, sparse_cap, st));
     d_order = p_order;
+    d_sparse = p_max + 1;
   }
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
-                        s->d_counters, d_order, false, blocks, threads, st));
+                        s->d_counters, d_order, d_sparse, false, blocks, threads, st));
   return RTMI_OK;
 }
 

@@ -825,6 +825,7 @@ struct LaunchCfg {
   int32_t coop_lanes;  // mesh search: the wave finishes together once at most this many lanes still search
   int32_t pad;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
+  const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every 16th lane only
 };
 
 template <uint32_t F>
@@ -877,6 +878,15 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   constexpr int kAttFloats = (F & F_TEX) ? RTMI_KERNEL_MAX_DEPTH * 3 : 3;
   float att[kAttFloats];
 
+  // Mesh variants, frames dominated by a few outlier tiles (their pixels bounce to the depth limit
+  // inside the mesh, tens of times the median cost): the frame time is the serial chain of the
+  // slowest pixel, and what shortens a chain is the wave-cooperative search, which needs few rays
+  // per wave.  The first sparse_limit work items (the outlier tiles, longest-first order) are
+  // therefore spread thin -- one pixel per kSparseStride lanes -- while the rest of the frame runs
+  // with full waves.
+  unsigned long long sparse_limit = 0ull;
+  if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
+
   for (;;) {
     // -------------------------------------------------------- sample / pixel bookkeeping
     if (!active && !done) {
@@ -901,6 +911,12 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         has_px = false;
       }
       while (!has_px && !done) {
+        if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (kSparseStride - 1)) != 0) {
+          // the head of the queue holds the outlier tiles: only every kSparseStride-th lane takes
+          // pixels there (the others look again next round), so that a wave carries few rays
+          // and the mesh search runs in its cooperative mode
+          if (__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sparse_limit) break;
+        }
         unsigned long long nq = atomicAdd(&counters[0], 1ull);
         if ((int64_t)nq >= n_items) {
           done = true;
@@ -956,7 +972,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         active = true;
       }
     }
-    if (!__any(active)) break;
+    if (!__any(active)) {
+      if (!(F & F_BVH) || __all(done)) break;
+      continue;  // lanes held back from the sparse head of the queue: it has just moved on
+    }
 
     Hit h = {};
     if (F & F_BVH)  // every lane goes in: see closest_hit
@@ -1207,17 +1226,36 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const uint32_t *__restri
 }
 
 // One workgroup: counting sort of the tiles into 256 cost buckets, most expensive bucket first.
+// Also sizes the "sparse" head of the queue (sparse_items, in work items; render_body, mesh
+// variants): the outlier tiles -- at least twice the mean cost, in a frame whose most expensive
+// tile costs at least three times the mean -- up to `sparse_cap` items, what the grid can hold at
+// one pixel per kSparseStride lanes.
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost,
                                                           const uint32_t *__restrict__ max_cost, int n_tiles,
-                                                          uint32_t *__restrict__ order) {
+                                                          uint32_t *__restrict__ order,
+                                                          uint32_t *__restrict__ sparse_items, uint32_t sparse_cap) {
   __shared__ uint32_t bins[256];
   __shared__ uint32_t base[256];
+  __shared__ unsigned long long total;
+  __shared__ uint32_t outliers;
   for (int i = threadIdx.x; i < 256; i += blockDim.x) bins[i] = 0;
+  if (threadIdx.x == 0) total = 0ull, outliers = 0u;
   __syncthreads();
   const uint32_t mx = *max_cost > 0 ? *max_cost : 1;
+  unsigned long long part = 0ull;
   for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
     uint32_t b = 255u - (uint32_t)(((unsigned long long)cost[t] * 255ull) / mx);  // bucket 0 = most expensive
     atomicAdd(&bins[b], 1u);
+    part += cost[t];
+  }
+  atomicAdd(&total, part);
+  __syncthreads();
+  {
+    const unsigned long long sum = total;  // mean = sum / n_tiles; compare cost * n_tiles with k * sum
+    uint32_t mine = 0;
+    for (int t = threadIdx.x; t < n_tiles; t += blockDim.x)
+      if ((unsigned long long)cost[t] * (unsigned long long)n_tiles >= 2ull * sum) mine++;
+    if (mine) atomicAdd(&outliers, mine);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1226,6 +1264,9 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
       base[i] = run;
       run += bins[i];
     }
+    const bool skewed = (unsigned long long)mx * (unsigned long long)n_tiles >= 3ull * total;
+    const uint32_t items = outliers * 64u;
+    *sparse_items = skewed ? (items < sparse_cap ? items : sparse_cap) : 0u;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < n_tiles; t += blockDim.x) {
@@ -1235,12 +1276,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 }
 
 hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
-                             uint32_t *d_order, hipStream_t stream) {
+                             uint32_t *d_order, uint32_t sparse_cap, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
                      d_max);
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order, d_max + 1,
+                     sparse_cap);
   return hipGetLastError();
 }
 
@@ -1316,10 +1358,12 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
 template <uint32_t F>
 static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                                   uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                                  bool probe, int blocks, int threads, hipStream_t stream) {
+                                  const uint32_t *d_sparse_items, bool probe, int blocks, int threads,
+                                  hipStream_t stream) {
   size_t lds = 0;
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
   lc.tile_order = d_tile_order;
+  lc.sparse_items = d_sparse_items;
   if (probe) {
     hipLaunchKernelGGL(probe_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
                        d_ray_counts, d_counters);
@@ -1367,11 +1411,11 @@ int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, i
 
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                         bool probe, int blocks, int threads, hipStream_t stream) {
+                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, hipStream_t stream) {
 #define X(V) \
   if (variant == (uint32_t)(V)) \
-    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, d_tile_order, probe, blocks, \
-                                threads, stream);
+    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, d_tile_order, d_sparse_items, probe, \
+                                blocks, threads, stream);
   RTMI_FOR_EACH_VARIANT(X)
 #undef X
   return hipErrorInvalidValue;

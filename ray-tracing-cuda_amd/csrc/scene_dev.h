@@ -100,6 +100,7 @@ constexpr int kHitWords = 4;   // words per entry: code, face, t (one or two wor
 constexpr int kBvhLdsWords = kSubStack + kHitSlots * kHitWords;  // LDS words per lane
 constexpr int kCoopLanes = 16;   // cooperative finish once at most this many lanes still search (>= 4 lanes each)
 constexpr int kCoopStack = 512;  // per-wave LDS words of the cooperative finish, split evenly between its groups
+constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
 constexpr int kRefDepthMax = 32;  // decisions below the root that a leaf's path code can hold
 
 struct BvhRec {  // one per BVH hitable
