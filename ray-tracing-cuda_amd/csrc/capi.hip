@@ -509,7 +509,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
     HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, nullptr, true,
                           blocks, threads, st));
-    const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / kSparseStride) / 64 * 64);
+    const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / sparse_stride()) / 64 * 64);
     HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, sparse_cap, st));
     d_order = p_order;
     d_sparse = p_max + 1;

@@ -26,6 +26,7 @@ hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &f
                          const uint32_t *d_sparse_items, bool probe, int blocks, int threads, hipStream_t stream);
 // Tiles sorted by descending cost (sum of 64 ray counts each); d_cost/d_order hold n_tiles words,
 // d_max two (the largest cost, the sparse item count).
+int sparse_stride();
 // sparse_cap: work items the grid holds at one pixel per kSparseStride lanes (a multiple of 64).
 hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
                              uint32_t *d_order, uint32_t sparse_cap, hipStream_t stream);

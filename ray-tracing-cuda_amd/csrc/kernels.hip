@@ -826,6 +826,7 @@ struct LaunchCfg {
   int32_t pad;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every 16th lane only
+  int32_t sparse_stride;
 };
 
 template <uint32_t F>
@@ -911,7 +912,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         has_px = false;
       }
       while (!has_px && !done) {
-        if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (kSparseStride - 1)) != 0) {
+        if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (uint32_t)(lc.sparse_stride - 1)) != 0) {
           // the head of the queue holds the outlier tiles: only every kSparseStride-th lane takes
           // pixels there (the others look again next round), so that a wave carries few rays
           // and the mesh search runs in its cooperative mode
@@ -1233,7 +1234,8 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const uint32_t *__restri
 __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__restrict__ cost,
                                                           const uint32_t *__restrict__ max_cost, int n_tiles,
                                                           uint32_t *__restrict__ order,
-                                                          uint32_t *__restrict__ sparse_items, uint32_t sparse_cap) {
+                                                          uint32_t *__restrict__ sparse_items, uint32_t sparse_cap,
+                                                          uint32_t outlier_x10) {
   __shared__ uint32_t bins[256];
   __shared__ uint32_t base[256];
   __shared__ unsigned long long total;
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
     const unsigned long long sum = total;  // mean = sum / n_tiles; compare cost * n_tiles with k * sum
     uint32_t mine = 0;
     for (int t = threadIdx.x; t < n_tiles; t += blockDim.x)
-      if ((unsigned long long)cost[t] * (unsigned long long)n_tiles >= 2ull * sum) mine++;
+      if ((unsigned long long)cost[t] * (unsigned long long)n_tiles * 10ull >= (unsigned long long)outlier_x10 * sum) mine++;
     if (mine) atomicAdd(&outliers, mine);
   }
   __syncthreads();
@@ -1282,7 +1284,7 @@ hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
                      d_max);
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order, d_max + 1,
-                     sparse_cap);
+                     sparse_cap, (uint32_t)(getenv("RTMI_OUTLIER_X10") ? atoi(getenv("RTMI_OUTLIER_X10")) : 20));
   return hipGetLastError();
 }
 
@@ -1332,6 +1334,12 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
   return hipGetLastError();
 }
 
+int sparse_stride() {
+  const char *e = getenv("RTMI_SPARSE_STRIDE");  // tuning knob
+  int v = e ? atoi(e) : kSparseStride;
+  return (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : kSparseStride;
+}
+
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
   LaunchCfg lc{};
   lc.tile_order = nullptr;
@@ -1364,6 +1372,7 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
   lc.tile_order = d_tile_order;
   lc.sparse_items = d_sparse_items;
+  lc.sparse_stride = sparse_stride();
   if (probe) {
     hipLaunchKernelGGL(probe_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
                        d_ray_counts, d_counters);
