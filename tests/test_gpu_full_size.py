@@ -61,6 +61,34 @@ def test_c3_bunny_mesh_1024sq_sampled_pixels():
     assert (g_rays.reshape(-1)[ids] > spp).any()  # some sampled pixels do bounce off the mesh
 
 
+def test_c3_outlier_spreading_and_queue_order_change_no_pixel():
+    """At 64 spp the mesh frame goes through the scheduler: the 2-spp probe, the longest-first tile
+    order and -- its cost distribution being skewed -- the outlier tiles spread one pixel per 16 lanes
+    with cooperative searches.  None of it may change a value: the frame equals the image-order
+    render bit for bit (image, ray counts, ray total), and sampled pixels equal the oracle."""
+    import rtmi
+    from rtmi import scenes
+    h = w = 1024
+    spp, depth = 64, 10
+    faces = scenes.procedural_bunny_mesh()
+    try:
+        assert rtmi.lib().rtmi_set_schedule(0) == 0
+        plain = common.gpu_render("bunny", h, w, spp, depth, faces=faces)
+        assert rtmi.lib().rtmi_set_schedule(1) == 0
+        sched = common.gpu_render("bunny", h, w, spp, depth, faces=faces)
+    finally:
+        rtmi.lib().rtmi_set_schedule(1)
+    assert np.array_equal(plain[0], sched[0]) and np.array_equal(plain[1], sched[1]) and plain[3] == sched[3]
+    rays = sched[1].reshape(-1)
+    tiles = rays.reshape(h // 8, 8, w // 8, 8).sum(axis=(1, 3)).reshape(-1)
+    assert tiles.max() >= 3 * tiles.mean()  # the distribution that switches the outlier spreading on
+    heavy = np.argsort(-rays)[:24].astype(np.int32)  # the heaviest pixels are the ones that were spread
+    ids = np.unique(np.concatenate([heavy, np.random.default_rng(3).integers(0, h * w, 24).astype(np.int32)]))
+    o_rgb, o_rays = _oracle_pixels("bunny", h, w, spp, depth, ids, faces=faces)
+    assert np.array_equal(rays[ids], o_rays)
+    assert np.array_equal(sched[0].reshape(-1, 3)[ids], o_rgb)
+
+
 def test_c4_c5_shapes_sampled_pixels():
     """configs[3] (cornell 2048^2) and configs[4] (birthday 4096^2) frame shapes at reduced spp,
     rendered as 8 shards; sampled pixels vs the oracle (birthday within the texel tolerance)."""
