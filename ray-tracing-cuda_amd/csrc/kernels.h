@@ -19,15 +19,15 @@ uint32_t pick_variant(uint32_t features);
 int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads);
 // d_tile_order (nullable): the work queue hands out local tile d_tile_order[k] as its k-th tile.
 // d_sparse_items (nullable; needs d_tile_order): device word, how many leading work items are outlier
-// tiles that mesh kernels spread one pixel per 16 lanes (launch_tile_order writes it to d_max[1]).
+// tiles that mesh kernels spread one pixel per sparse_stride() lanes (launch_tile_order writes it to d_max[1]).
 // probe: launch under the probe_kernel name (the scheduler's cost-estimation pass).
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
                          const uint32_t *d_sparse_items, bool probe, int blocks, int threads, hipStream_t stream);
 // Tiles sorted by descending cost (sum of 64 ray counts each); d_cost/d_order hold n_tiles words,
 // d_max two (the largest cost, the sparse item count).
-int sparse_stride();
-// sparse_cap: work items the grid holds at one pixel per kSparseStride lanes (a multiple of 64).
+int sparse_stride();  // kSparseStride, or the RTMI_SPARSE_STRIDE tuning override
+// sparse_cap: work items the grid holds at one pixel per sparse_stride() lanes (a multiple of 64).
 hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
                              uint32_t *d_order, uint32_t sparse_cap, hipStream_t stream);
 

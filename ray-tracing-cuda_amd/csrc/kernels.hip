@@ -825,8 +825,8 @@ struct LaunchCfg {
   int32_t coop_lanes;  // mesh search: the wave finishes together once at most this many lanes still search
   int32_t pad;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
-  const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every 16th lane only
-  int32_t sparse_stride;
+  const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
+  int32_t sparse_stride;         // power of two; kSparseStride unless RTMI_SPARSE_STRIDE overrides it
 };
 
 template <uint32_t F>
@@ -883,7 +883,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // inside the mesh, tens of times the median cost): the frame time is the serial chain of the
   // slowest pixel, and what shortens a chain is the wave-cooperative search, which needs few rays
   // per wave.  The first sparse_limit work items (the outlier tiles, longest-first order) are
-  // therefore spread thin -- one pixel per kSparseStride lanes -- while the rest of the frame runs
+  // therefore spread thin -- one pixel per lc.sparse_stride lanes -- while the rest of the frame runs
   // with full waves.
   unsigned long long sparse_limit = 0ull;
   if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
@@ -913,7 +913,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       }
       while (!has_px && !done) {
         if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (uint32_t)(lc.sparse_stride - 1)) != 0) {
-          // the head of the queue holds the outlier tiles: only every kSparseStride-th lane takes
+          // the head of the queue holds the outlier tiles: only every sparse_stride-th lane takes
           // pixels there (the others look again next round), so that a wave carries few rays
           // and the mesh search runs in its cooperative mode
           if (__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sparse_limit) break;
