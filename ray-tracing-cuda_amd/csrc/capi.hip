@@ -473,8 +473,17 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     }
     n_cu = it->second;
   }
-  const int threads = g_threads > 0 ? g_threads : 256;
   const uint32_t variant = pick_variant(s->features);
+  int threads = g_threads > 0 ? g_threads : 256;
+  if (g_threads <= 0 && (variant & F_BVH)) {
+    // mesh variants keep ~310 B of LDS per lane plus per-workgroup tables: when a deep id stack leaves
+    // room for one 256-lane workgroup only, smaller workgroups keep more lanes resident
+    int best = 0;
+    for (int t = 256; t >= 64; t /= 2) {
+      const int lanes = t * render_occupancy(variant, s->dev, d, t);
+      if (lanes > best) best = lanes, threads = t;
+    }
+  }
   int per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : render_occupancy(variant, s->dev, d, threads);
   if (per_cu <= 0) per_cu = 1;
   int64_t want = (d.items + threads - 1) / threads;
