@@ -160,3 +160,52 @@ def test_many_hit_leaves_along_one_ray(case):
     assert R.total_rays() == o_total
     assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
     assert np.array_equal(img.cpu().numpy(), o_rgb), np.abs(img.cpu().numpy() - o_rgb).max()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
+    """Mesh-heavy random worlds rendered three ways -- image order, forced longest-first (probe,
+    outlier spreading, cooperative searches wherever the cost distribution is skewed), and as two
+    interleaved shards -- must give the same image, ray counts and ray total bit for bit.  (The
+    oracle comparison of such worlds is test_random_world_bit_exact; this one is large enough for
+    the scheduler to matter: 192x256 at 64 spp.)"""
+    import torch
+    from rtmi.scenes import procedural_bunny_mesh
+    rng = np.random.default_rng(500 + seed)
+    h, w, spp, depth = 192, 256, 64, int(rng.choice([6, 12, 30]))
+    b = rtmi.SceneBuilder(90 + seed)
+    b.camera_pinhole(v3(0.0, 0.16, -0.55), v3(0.0, 0.1, 0.0), v3(0, 1, 0), PI_D / 4, w / h)
+    mats = [b.lambertian(v3(1, 1, 1)), b.metal(v3(0.9, 0.85, 0.8), 0.05), b.dielectric(v3(0.95, 0.95, 1.0), 1.4)]
+    mesh = procedural_bunny_mesh(int(rng.integers(10, 24)))
+    for k in range(int(rng.integers(1, 4))):
+        off = np.array([0.17 * (k - 1), 0.0, 0.05 * k], dtype=np.float32)
+        b.bvh((mesh + off).astype(np.float32), mats[int(rng.integers(0, 3))], k_min=int(rng.choice([4, 64, 2048])))
+    if seed % 2:
+        b.sphere(v3(0, -100.0 + 0.03, 0), 100.0, b.lambertian(v3(0.5, 0.6, 0.5)))
+    else:
+        b.parallelogram([v3(-5, 0.03, -5), v3(5, 0.03, -5), v3(-5, 0.03, 5)], b.lambertian(v3(0.5, 0.6, 0.5)))
+    b.sky()
+    b.commit()
+
+    def run(world):
+        tiles, counts, total = [], [], 0
+        for r in range(world):
+            R = rtmi.Renderer(b, h, w, spp, depth, True, rank=r, world_size=world).init_rng()
+            R.render()
+            total += R.total_rays()
+            tiles.append(R.tiles), counts.append(R.ray_counts)
+        img, cnt = R.untile(torch.cat(tiles, 0).contiguous(), torch.cat(counts, 0).contiguous())
+        torch.cuda.synchronize()
+        return img.cpu().numpy(), cnt.cpu().numpy(), total
+
+    try:
+        assert rtmi.lib().rtmi_set_schedule(0) == 0
+        plain = run(1)
+        assert rtmi.lib().rtmi_set_schedule(2) == 0
+        forced = run(1)
+        sharded = run(2)
+    finally:
+        rtmi.lib().rtmi_set_schedule(1)
+    for other in (forced, sharded):
+        assert np.array_equal(plain[0], other[0]) and np.array_equal(plain[1], other[1]) and plain[2] == other[2]
+    assert plain[2] > h * w * spp * 1.2
