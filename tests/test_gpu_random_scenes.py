@@ -164,9 +164,10 @@ def test_many_hit_leaves_along_one_ray(case):
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
-    """Mesh-heavy random worlds rendered three ways -- image order, forced longest-first (probe,
-    outlier spreading, cooperative searches wherever the cost distribution is skewed), and as two
-    interleaved shards -- must give the same image, ray counts and ray total bit for bit.  (The
+    """Mesh-heavy random worlds rendered five ways -- image order, forced longest-first (probe,
+    outlier spreading, cooperative searches wherever the cost distribution is skewed), as two
+    interleaved shards, and with the cooperative search switched off or limited to the last three
+    lanes -- must give the same image, ray counts and ray total bit for bit.  (The
     oracle comparison of such worlds is test_random_world_bit_exact; this one is large enough for
     the scheduler to matter: 192x256 at 64 spp.)"""
     import torch
@@ -198,14 +199,20 @@ def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
         torch.cuda.synchronize()
         return img.cpu().numpy(), cnt.cpu().numpy(), total
 
+    import os
     try:
         assert rtmi.lib().rtmi_set_schedule(0) == 0
         plain = run(1)
         assert rtmi.lib().rtmi_set_schedule(2) == 0
         forced = run(1)
         sharded = run(2)
+        os.environ["RTMI_COOP_LANES"] = "0"  # tuning knob: every search finished by its own lane
+        solo = run(1)
+        os.environ["RTMI_COOP_LANES"] = "3"  # ... or only the last three by the wave
+        few = run(1)
     finally:
+        os.environ.pop("RTMI_COOP_LANES", None)
         rtmi.lib().rtmi_set_schedule(1)
-    for other in (forced, sharded):
+    for other in (forced, sharded, solo, few):
         assert np.array_equal(plain[0], other[0]) and np.array_equal(plain[1], other[1]) and plain[2] == other[2]
     assert plain[2] > h * w * spp * 1.2
