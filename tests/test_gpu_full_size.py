@@ -106,3 +106,24 @@ def test_c4_c5_shapes_sampled_pixels():
     o_rgb, o_rays = _oracle_pixels("birthday", h, w, 1, 10, ids, earthmap=tex)
     assert np.array_equal(g_rays.reshape(-1)[ids], o_rays)
     assert common.rel_l2(g_rgb.reshape(-1, 3)[ids], o_rgb) <= 1e-3
+
+
+def test_million_face_mesh_sampled_pixels():
+    """1.08 M faces: 2,047 reference-tree nodes (only the first 512 are staged in LDS), a search tree
+    ten levels deep (31 of the 32 stack entries the kernel has).  512x512 at 64 spp goes through the
+    scheduler; sampled pixels, the heaviest included, equal the oracle bit for bit."""
+    from rtmi import scenes
+    h = w = 512
+    spp, depth = 64, 10
+    faces = scenes.procedural_bunny_mesh(300)
+    assert faces.shape[0] == 1_080_000
+    g_rgb, g_rays, _, g_total, b = common.gpu_render("bunny", h, w, spp, depth, faces=faces)
+    st = b.stats()
+    assert st["bvh_nodes"] == 2047 and st["bvh_faces"] >= 1_080_000
+    rays = g_rays.reshape(-1)
+    ids = np.unique(np.concatenate([np.argsort(-rays)[:10], np.random.default_rng(1).integers(0, h * w, 14),
+                                    [256 * w + 256, 250 * w + 260]])).astype(np.int32)
+    o_rgb, o_rays = _oracle_pixels("bunny", h, w, spp, depth, ids, faces=faces)
+    assert np.array_equal(rays[ids], o_rays)
+    assert np.array_equal(g_rgb.reshape(-1, 3)[ids], o_rgb)
+    assert rays[ids].max() > 2 * spp
