@@ -327,6 +327,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.n_runs = (int)s->runs.size();
   d.n_mats = (int)s->mat_recs.size();
   d.n_nodes = (int)s->nodes.size();
+  d.sub_stack = s->sub_depth > 0 ? 3 * s->sub_depth + 1 : 0;
   d.unsigned_colours = 1;
   for (const MatRec &m : s->mat_recs) {
     const float c[3] = {m.r, m.g, m.b};

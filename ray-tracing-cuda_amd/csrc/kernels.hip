@@ -382,12 +382,14 @@ __device__ __forceinline__ int lane_bcast(int x, int lane) { return __builtin_am
 // once) and cheaper (a quarter of the arithmetic per lane).  Hits go to the owner's list.
 template <typename T, bool DT, int LG>
 __device__ __forceinline__ void coop_finish(const SceneDev &sc, unsigned long long busy, const int *s_substack,
-                                            int *wstack, int *hits, int nthr, V3 o, V3 d, V3 inv_d, float lo0, float hi0,
-                                            T bt_to, int stop, int &cnt, int64_t lo_code, int64_t &cut) {
+                                            int *wstack, int *hits, int nthr, int sub_stack, V3 o, V3 d, V3 inv_d,
+                                            float lo0, float hi0, T bt_to, int stop, int &cnt, int64_t lo_code,
+                                            int64_t &cut) {
   constexpr int kGroups = 64 / LG, kEntries = LG / 4, kSegment = kCoopStack / kGroups;
   // kEntries per step only while the segment is sure to hold what they can push (4 each) plus
-  // the depth-first remainder of one-entry steps (at most kSubStack - 1 above the switch point)
-  constexpr int kWideMax = kSegment - 3 * kEntries - (kSubStack - 1);
+  // the depth-first remainder of one-entry steps (at most sub_stack - 1 above the switch point);
+  // the caller only picks an LG whose segment holds sub_stack entries
+  const int wide_max = kSegment - 3 * kEntries - (sub_stack - 1);
   const int lane = (int)(threadIdx.x & 63u), wave_tid0 = (int)(threadIdx.x & ~63u);
   const int grp = lane / LG, gl = lane % LG, ent = gl >> 2, sub = gl & 3;
   int owner = -1;
@@ -419,7 +421,7 @@ __device__ __forceinline__ void coop_finish(const SceneDev &sc, unsigned long lo
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
   while (__ballot(size > 0) != 0ull) {
-    const int want = (kEntries > 1 && size <= kWideMax) ? kEntries : 1;
+    const int want = (kEntries > 1 && size <= wide_max) ? kEntries : 1;
     const int width = size < want ? size : want;
     const bool mine = ent < width;
     int e = 0;
@@ -633,8 +635,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
       const int nthr = blockDim.x;
       int *sstack = s_substack + threadIdx.x;                                // [level][thread]
-      int *hits = s_substack + (size_t)kSubStack * nthr + threadIdx.x;       // [slot][word][thread]
-      int *wstack = s_substack + (size_t)kBvhLdsWords * nthr + (size_t)(threadIdx.x >> 6) * kCoopStack;
+      int *hits = s_substack + (size_t)sc.sub_stack * nthr + threadIdx.x;    // [slot][word][thread]
+      int *wstack = s_substack + (size_t)(sc.sub_stack + kHitListWords) * nthr + (size_t)(threadIdx.x >> 6) * kCoopStack;
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
         T bt_to = t_to;
@@ -663,13 +665,13 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
               // more lanes work for each of them
               const int left = __popcll(busy);
               if (left <= 4)
-                coop_finish<T, DT, 16>(sc, busy, s_substack, wstack, hits, nthr, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
+                coop_finish<T, DT, 16>(sc, busy, s_substack, wstack, hits, nthr, sc.sub_stack, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
                                        lo_code, cut);
               else if (left <= 8)
-                coop_finish<T, DT, 8>(sc, busy, s_substack, wstack, hits, nthr, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
+                coop_finish<T, DT, 8>(sc, busy, s_substack, wstack, hits, nthr, sc.sub_stack, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
                                       lo_code, cut);
               else
-                coop_finish<T, DT, 4>(sc, busy, s_substack, wstack, hits, nthr, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
+                coop_finish<T, DT, 4>(sc, busy, s_substack, wstack, hits, nthr, sc.sub_stack, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
                                       lo_code, cut);
               stop = 0;
               break;
@@ -1347,6 +1349,9 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
     const char *e = getenv("RTMI_COOP_LANES");  // tuning knob
     lc.coop_lanes = e ? atoi(e) : kCoopLanes;
     if (lc.coop_lanes > kCoopLanes) lc.coop_lanes = kCoopLanes;  // one group of >= 4 lanes per finishing search
+    // ... whose segment of the wave-wide stack (kCoopStack / groups words) must hold a whole per-lane stack
+    while (lc.coop_lanes > 0 && kCoopStack / (lc.coop_lanes > 8 ? 16 : lc.coop_lanes > 4 ? 8 : 4) < sc.sub_stack)
+      lc.coop_lanes = lc.coop_lanes > 8 ? 8 : lc.coop_lanes > 4 ? 4 : 0;
     if (lc.coop_lanes < 0) lc.coop_lanes = 0;
   }
   lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
@@ -1359,7 +1364,7 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
   size_t soff = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
   lc.substack_off = (int32_t)soff;
-  *lds_bytes = soff + ((variant & F_BVH) ? ((size_t)kBvhLdsWords * threads + (size_t)(threads / 64) * kCoopStack) * sizeof(int) : 0);
+  *lds_bytes = soff + ((variant & F_BVH) ? ((size_t)(sc.sub_stack + kHitListWords) * threads + (size_t)(threads / 64) * kCoopStack) * sizeof(int) : 0);
   return lc;
 }
 

@@ -377,7 +377,7 @@ std::string Scene::flatten() {
         if (ref_depth > kRefDepthMax) return "mesh tree too deep for the kernel's leaf path codes";
         br.sub_root = hb.n > 0 ? build_subtree(local_sub, fp, 0, hb.n, &depth) + sub_base : -1;
         sub_depth = std::max(sub_depth, depth);
-        if (3 * depth + 1 > kSubStack) return "mesh too deep for the kernel's search stack";
+        if (3 * depth + 1 > kSubStackMax) return "mesh too deep for the kernel's search stack";
         const int node_base = (int)nodes.size();
         for (BvhNode nd : local_nodes) {  // rebase indices into the scene-wide arrays
           if (nd.right >= 0) nd.left += node_base, nd.right += node_base;

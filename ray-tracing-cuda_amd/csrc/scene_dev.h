@@ -94,10 +94,11 @@ struct alignas(16) SubNode4 {  // 128 B
   int32_t child[4];
   int32_t pad[4];
 };
-constexpr int kSubStack = 32;  // per-lane search stack entries (LDS); 3 * depth + 1 must fit
+constexpr int kSubStackMax = 128;  // most per-lane search stack entries (LDS) a scene may need: 3 * depth + 1 of its
+                                  // deepest search tree (SceneDev::sub_stack; 25 for the 69 k-face mesh, 31 for 1 M faces)
 constexpr int kHitSlots = 8;   // per-lane candidate list: one (code, face, t) entry per leaf holding a hit
 constexpr int kHitWords = 4;   // words per entry: code, face, t (one or two words)
-constexpr int kBvhLdsWords = kSubStack + kHitSlots * kHitWords;  // LDS words per lane
+constexpr int kHitListWords = kHitSlots * kHitWords;  // LDS words per lane next to the search stack
 constexpr int kCoopLanes = 16;   // cooperative finish once at most this many lanes still search (>= 4 lanes each)
 constexpr int kCoopStack = 512;  // per-wave LDS words of the cooperative finish, split evenly between its groups
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
@@ -144,6 +145,7 @@ struct SceneDev {
   const MatRec *mats;
   const TexRec *texs;
   int32_t n_runs, n_mats, n_nodes;
+  int32_t sub_stack;  // per-lane search stack entries this scene needs (0 without meshes)
   int32_t unsigned_colours;  // 1: no material colour has its sign bit set (not even -0): then every layer
                              // product is +0, positive or NaN and `emitted(0) + product` is the product itself
   CameraDev cam;
