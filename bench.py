@@ -1,23 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — Mrays/s of the path-tracing hot path on MI355X.
 
-One *step* = one frame of the workload through the C ABI: trace kernel for this rank's
-pixel tiles (+ RCCL gather of the tile buffers to rank 0 and the untile kernel when
-N > 1).  Inputs (scene, RNG states) are resident in HBM before the timed region.
+One *step* = one frame of the workload through the C ABI: the trace kernel for this rank's
+pixel tiles, plus (N > 1) the RCCL gather of the tile buffers to rank 0 and the untile
+kernel.  Scene and RNG states are resident in HBM before the timed region.
 
-Workload at N=1 (BASELINE.json configs[1]): scenes/cornell_box, 1024x1024, 1024 spp,
-depth limit 50, seed 1024.  For N > 1 the job is weak-scaled: the same scene and aspect
-at side 1024*sqrt(N) (rounded to a multiple of 8), so every GPU keeps 1024^2 pixels of
-1024 spp; tiles are interleaved over ranks and nothing but the final gather is exchanged.
+Workloads (BASELINE.json ``configs``; scene constants are the reference's InitWorld literals):
+  c2  scenes/cornell_box 1024x1024 x1024 spp depth 50      — the N=1 line (configs[1])
+  c3  scenes/bunny (stand-in mesh) 1024x1024 x512 spp d10   — reported under config.extra at N=1
+  c4  scenes/cornell_box 2048x2048 x4096 spp depth 50       — the N>1 line: FIXED frame, strong scaling
+  c5  scenes/birthday 4096x4096 x8192 spp depth 10
+``--workload auto`` (default) picks c2 for N=1 and c4 for N>1.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), including
-  roofline     — algorithmic bytes per launch (rays x bytes/ray) over the
-                 trace kernel's mean duration measured with HIP events on its stream;
-  cpu_baseline — the CPU oracle ("port") on this box's cores on a bounded sample.
+Launch: ``python bench.py --gpus N`` starts its own N ranks (one process per GPU, before any
+GPU call in the parent) unless it already runs under ``python -m torch.distributed.run``
+(RANK/WORLD_SIZE set).  It never runs fewer ranks than asked for.
+
+Prints ONE JSON line on rank 0, including
+  roofline     — the bound the counters support: VALU issue.  ``achieved`` = issue cycles per SIMD
+                 per launch = (2 x VALU + 6 x transcendental wave-instructions per 64 rays, from the
+                 committed rocprofv3 PMC digest profiles/roofline_inputs.json) x this run's rays / 64
+                 / SIMDs; ``peak`` = the kernel's duration measured here with HIP events x 2.4 GHz.
+                 ``hbm`` keeps the SURVEY 8(d) algorithmic-bytes figure and ``traffic`` is the
+                 FETCH_SIZE+WRITE_SIZE bytes per launch of the same workload from that digest.
+  cpu_baseline — the CPU oracle ("port") on this box's cores, on SURVEY 8(d)'s two samples.
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -26,105 +35,156 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "ray-tracing-cuda_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+CLOCK_GHZ = 2.4        # ... max clock 2400 MHz
+CYC_VALU, CYC_TRANS = 2, 8  # issue cycles per wave-instruction on a SIMD-32 (same guide)
+
+WORKLOADS = {
+    "c2": dict(scene="cornell_box", size=1024, spp=1024, depth=50),
+    "c3": dict(scene="bunny", size=1024, spp=512, depth=10),
+    "c4": dict(scene="cornell_box", size=2048, spp=4096, depth=50),
+    "c5": dict(scene="birthday", size=4096, spp=8192, depth=10),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell_box", choices=["cornell_box", "spheres", "bunny", "birthday"])
-    ap.add_argument("--size", type=int, default=1024, help="per-GPU frame side (pixels)")
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
+    ap.add_argument("--scene", default=None, choices=["cornell_box", "spheres", "bunny", "birthday"])
+    ap.add_argument("--size", type=int, default=None, help="frame side in pixels (the WHOLE frame, for any N)")
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="256x256x32",
-                    help="HxWxSPP of the CPU-baseline sample (default: 256x256, spp sized for ~15 s)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config.extra C3 line")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
-    return ap.parse_args()
+    ap.add_argument("--selftest-exchange", action="store_true",
+                    help="CPU-only check of the launcher + the N-rank exchange (gloo, no rendering)")
+    return ap.parse_args(argv)
 
 
-def build_scene(rtmi, name, aspect, seed):
+def pick_workload(args, world):
+    name = args.workload
+    if name == "auto":
+        name = "c2" if world == 1 else "c4"
+    w = dict(WORKLOADS[name])
+    custom = False
+    for k in ("scene", "size", "spp", "depth"):
+        v = getattr(args, k)
+        if v is not None and v != w[k]:
+            w[k] = v
+            custom = True
+    w["name"] = "custom" if custom else name
+    return w
+
+
+def build_scene(builder, name, aspect):
     from rtmi import scenes
-    b = rtmi.SceneBuilder(seed)
     if name == "cornell_box":
-        scenes.cornell_box(b, aspect)
+        scenes.cornell_box(builder, aspect)
     elif name == "spheres":
-        scenes.spheres(b, aspect)
+        scenes.spheres(builder, aspect)
     elif name == "bunny":
-        scenes.bunny(b, aspect, scenes.procedural_bunny_mesh())
+        scenes.bunny(builder, aspect, scenes.procedural_bunny_mesh())
     elif name == "birthday":
-        scenes.birthday(b, aspect, scenes.procedural_earthmap(1024, 2048))
-    return b
+        scenes.birthday(builder, aspect, scenes.procedural_earthmap(1024, 2048))
+    return builder
 
 
-def cpu_baseline(args, name, seed):
-    """Oracle (CPU restatement, kind "port") on the host cores, bounded sample of the same workload."""
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, int(q / p + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement, kind "port") on SURVEY 8(d)'s two samples: C1 = spheres
+    256x256 x16 spp depth 8 (configs[0]) and a reduced C2 = cornell_box 256x256 x64 spp depth 50.
+    RNG seeding is outside the timed region, as the reference's kernel-only timing is
+    (utils.cu:155-170).  ``value`` is the reduced-C2 rate (the scene of the N=1 line)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
     from rtmi import scenes
-    h, w, spp = (int(x) for x in args.cpu_sample.split("x"))
-    b = oraclelib.OracleBuilder(seed)
-    if name == "cornell_box":
-        scenes.cornell_box(b, w / h)
-    elif name == "spheres":
-        scenes.spheres(b, w / h)
-    elif name == "bunny":
-        scenes.bunny(b, w / h, scenes.procedural_bunny_mesh())
-    else:
-        scenes.birthday(b, w / h, scenes.procedural_earthmap(1024, 2048))
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    # pilot run to size the sample for roughly 15 s of CPU work (bounded 10-30 s)
-    t0 = time.time()
-    _, _, _, rays0 = b.render(128, 128, 8, args.depth, threads=cores)
-    rate = rays0 / max(time.time() - t0, 1e-3)
-    rays_per_sample = rays0 / (128 * 128 * 8)
-    spp = int(max(4, min(8192, 15.0 * rate / (h * w * rays_per_sample))))
-    if args.cpu_sample != "256x256x32":
-        spp = int(args.cpu_sample.split("x")[2])
-    t0 = time.time()
-    _, _, _, rays = b.render(h, w, spp, args.depth, threads=cores)
-    dt = time.time() - t0
-    if dt < 8.0 and args.cpu_sample == "256x256x32":  # the pilot under-estimated the rate: one re-run, sized from dt
-        spp = int(min(8192, spp * 14.0 / max(dt, 0.1)))
+    cores = host_cores()
+    res = {}
+    for tag, name, side, spp, depth in (("c1_spheres_256x256x16_d8", "spheres", 256, 16, 8),
+                                        ("c2_reduced_cornell_256x256x64_d50", "cornell_box", 256, 64, 50)):
+        seed = scenes.SCENE_SEEDS[name]
+        b = build_scene(oraclelib.OracleBuilder(seed), name, 1.0)
+        states = oraclelib.rng_init(seed, side * side)
+        states[0] = b.state0
         t0 = time.time()
-        _, _, _, rays = b.render(h, w, spp, args.depth, threads=cores)
+        _, _, _, rays = b.render(side, side, spp, depth, threads=cores, states=states)
         dt = time.time() - t0
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%s %dx%d x%dspp depth%d, %d rays in %.1fs (oracle, g++ -O2 -ffp-contract=off, %d threads)" %
-                      (name, h, w, spp, args.depth, rays, dt, cores)}
+        res[tag] = {"mrays_per_s": rays / dt / 1e6, "rays": rays, "seconds": dt,
+                    "mrays_per_s_per_thread": rays / dt / 1e6 / cores}
+    main = res["c2_reduced_cornell_256x256x64_d50"]
+    return {"value": main["mrays_per_s"], "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "cornell_box 256x256 x64spp depth50: %d rays in %.1fs; spheres 256x256 x16spp depth8: %d rays in "
+                      "%.1fs (oracle, g++ -O2 -ffp-contract=off, %d threads, render loop only)" %
+                      (main["rays"], main["seconds"], res["c1_spheres_256x256x16_d8"]["rays"],
+                       res["c1_spheres_256x256x16_d8"]["seconds"], cores),
+            "samples": res}
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    import rtmi
+def roofline_inputs():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "roofline_inputs.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def roofline(w, rays_rank, kern_ms, bytes_per_ray, n_simd):
+    """VALU-issue roofline of the trace kernel on this rank (see the module docstring)."""
+    inp = roofline_inputs().get("kernels", {}).get(w["scene"])
+    hbm_alg = rays_rank * bytes_per_ray / (kern_ms * 1e-3) / 1e9
+    out = {"bound": "valu_issue", "achieved": None, "peak": kern_ms * 1e-3 * CLOCK_GHZ * 1e9, "unit": "cycles/SIMD",
+           "frac": None, "traffic": None,
+           "hbm": {"algorithmic_gbs": hbm_alg, "peak_gbs": HBM_PEAK_GBS, "algorithmic_frac": hbm_alg / HBM_PEAK_GBS,
+                   "note": "SURVEY 8(d) bytes/ray x rays / kernel time; these bytes are served from SGPRs / the "
+                           "scalar cache / LDS, not HBM (see traffic)"}}
+    if inp:
+        valu, trans = inp["valu_per_64_rays"], inp["trans_per_64_rays"]
+        cyc = (CYC_VALU * valu + (CYC_TRANS - CYC_VALU) * trans) * (rays_rank / 64.0) / n_simd
+        out.update(achieved=cyc, frac=cyc / out["peak"], valu_per_64_rays=valu, trans_per_64_rays=trans,
+                   clock_ghz=CLOCK_GHZ, n_simd=n_simd, source=inp.get("source"))
+        key = "%dx%dx%d_d%d" % (w["size"], w["size"], w["spp"], w["depth"])
+        tr = inp.get("hbm_bytes_per_launch", {}).get(key)
+        if tr is not None:
+            out["traffic"] = tr
+            out["hbm"]["measured_gbs"] = tr / (kern_ms * 1e-3) / 1e9
+            out["hbm"]["measured_frac"] = tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if out["frac"] > 1.0:
+            raise SystemExit("roofline.frac %.3f > 1: profiles/roofline_inputs.json does not describe the kernel that "
+                             "ran (regenerate it with tools/profile_bench.sh)" % out["frac"])
+    return out
+
+
+def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmup):
     from rtmi import scenes
-    from rtmi.dist import env_rank_world, gather_to_root
-
-    rank, local_rank, world = env_rank_world()
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run even with one rank
-    if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.blocks_per_cu or args.threads:
-        rtmi.lib().rtmi_set_launch(args.blocks_per_cu, args.threads)
-
-    side = int(round(args.size * math.sqrt(world) / 8.0)) * 8
-    H = W = side
-    seed = scenes.SCENE_SEEDS[args.scene]
-    scene = build_scene(rtmi, args.scene, W / H, seed).commit()
+    from rtmi.dist import gather_to_root
+    H = W = w["size"]
+    seed = scenes.SCENE_SEEDS[w["scene"]]
+    scene = build_scene(rtmi.SceneBuilder(seed), w["scene"], W / H).commit()
     bytes_per_ray = scene.bytes_per_ray()
-    R = rtmi.Renderer(scene, H, W, args.spp, args.depth, True, rank=rank, world_size=world)
+    R = rtmi.Renderer(scene, H, W, w["spp"], w["depth"], True, rank=rank, world_size=world)
     R.init_rng()
     pristine = R.states.clone()
     torch.cuda.synchronize()
@@ -143,14 +203,14 @@ def main():
         else:
             R.untile()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(events[i])
     if use_dist:
         dist.barrier()
@@ -158,46 +218,128 @@ def main():
     dt = time.perf_counter() - t0
 
     rays_rank = R.total_rays()  # rays of one step on this rank (identical every step)
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
-    tt = torch.tensor([dt, float(rays_rank), kern_ms], dtype=torch.float64, device="cuda")
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, steps)
+    per_rank_ms = [kern_ms]
+    rays_all = float(rays_rank)
+    n_seen = 1
     if use_dist:
+        tt = torch.tensor([dt, float(rays_rank), kern_ms], dtype=torch.float64, device="cuda")
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt = float(tmax[0])
-        rays_all = float(tsum[1])
-        kern_ms = float(tmax[2])
-    else:
-        rays_all = float(rays_rank)
+        allk = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        dist.all_gather(allk, tt[2:3].clone())
+        dt, rays_all = float(tmax[0]), float(tsum[1])
+        per_rank_ms = [float(x[0]) for x in allk]
+        n_seen = dist.get_world_size()
+    n_simd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * 4
+    return dict(H=H, W=W, seed=seed, dt=dt, rays_rank=rays_rank, rays_all=rays_all, kern_ms=kern_ms,
+                per_rank_ms=per_rank_ms, n_seen=n_seen, bytes_per_ray=bytes_per_ray, n_simd=n_simd)
+
+
+def selftest_exchange(args):
+    """The N-rank exchange of one step on CPU tensors over gloo: every rank fills its tile-major
+    buffer with the global pixel indices it owns, rank 0 gathers and untiles; no rendering."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from rtmi.dist import gather_to_root, shard_pixel_map, untile_host
+    from rtmi.launch import env_rank_world
+    rank, _, world = env_rank_world()
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h, w = 40, 56
+    pm = shard_pixel_map(h, w, rank, world)
+    tiles = np.full((pm.size, 3), -1.0, dtype=np.float32)
+    tiles[pm >= 0] = pm[pm >= 0, None].astype(np.float32) + np.array([0.0, 0.25, 0.5], dtype=np.float32)
+    allt = gather_to_root(torch.from_numpy(tiles), 0)
+    tot = torch.tensor([float((pm >= 0).sum())], dtype=torch.float64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    ok = int(tot.item()) == h * w
+    if rank == 0:
+        img = untile_host(allt.numpy(), h, w, world)
+        want = np.arange(h * w, dtype=np.float32).reshape(h, w, 1) + np.array([0.0, 0.25, 0.5], dtype=np.float32)
+        ok = ok and bool(np.array_equal(img, want))
+        print(json.dumps({"selftest": "ok" if ok else "FAILED", "n_gpus": world, "n_ranks_seen": dist.get_world_size(),
+                          "scaling": "strong"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(1)
+
+
+def main():
+    args = parse()
+    from rtmi import launch
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and not launch.under_launcher():
+        # become the launcher: N children, one per GPU, before this process touches a GPU
+        rc = launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:],
+                                need_gpus=not args.selftest_exchange)
+        raise SystemExit(rc)
+    if args.selftest_exchange:
+        if not launch.under_launcher():
+            os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                               "MASTER_PORT": str(launch.free_port())})
+        return selftest_exchange(args)
+
+    import torch
+    import torch.distributed as dist
+    import rtmi
+
+    rank, local_rank, world = launch.env_rank_world()
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: refusing to run a different number of ranks" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
+    torch.cuda.set_device(local_rank)
+    use_dist = launch.under_launcher()  # under torch.distributed.run even with one rank
+    if use_dist:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.blocks_per_cu or args.threads:
+        rtmi.lib().rtmi_set_launch(args.blocks_per_cu, args.threads)
+
+    w = pick_workload(args, world)
+    r = run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, args.steps, args.warmup)
 
     if rank == 0:
-        # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot
-        # run inside this process); scaled by this run's ray count, scene must match.
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-            if tj.get("workload_scene") == args.scene:
-                traffic = tj["hbm_bytes_per_ray"] * rays_rank
-        except (OSError, ValueError, KeyError):
-            pass
-        value = rays_all * args.steps / dt / 1e6
-        achieved = rays_rank * bytes_per_ray / (kern_ms * 1e-3) / 1e9  # GB/s, dominant kernel on this rank
+        value = r["rays_all"] * args.steps / r["dt"] / 1e6
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "warmup": args.warmup, "ms_per_step": r["dt"] / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "scenes/%s %dx%d x%dspp depth%d seed%d (%dx%d px per GPU, 8x8 tiles interleaved over %d "
-                            "rank(s))" % (args.scene, H, W, args.spp, args.depth, seed, args.size, args.size, world),
-                "rays_per_step": rays_all, "msamples_per_s": H * W * args.spp * args.steps / dt / 1e6,
-                "bytes_per_ray": bytes_per_ray, "kernel_ms": kern_ms,
+                "workload": "%s: scenes/%s %dx%d x%dspp depth%d seed%d (fixed frame; 8x8 tiles interleaved over %d "
+                            "rank(s); step = trace kernel%s)" %
+                            (w["name"], w["scene"], r["H"], r["W"], w["spp"], w["depth"], r["seed"], world,
+                             " + RCCL gather + untile" if world > 1 else " + untile"),
+                "rays_per_step": r["rays_all"], "msamples_per_s": r["H"] * r["W"] * w["spp"] * args.steps / r["dt"] / 1e6,
+                "bytes_per_ray": r["bytes_per_ray"], "kernel_ms": max(r["per_rank_ms"]),
+                "kernel_ms_per_rank": r["per_rank_ms"], "n_ranks_seen": r["n_seen"],
             },
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic},
+            "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"]),
         }
+    if world == 1 and not args.no_extra and w["name"] == "c2":
+        # BASELINE configs[2] (mesh + BVH) beside the headline: same contract, shorter run
+        w3 = dict(WORKLOADS["c3"], name="c3")
+        r3 = run_workload(rtmi, torch, dist, w3, args, rank, world, use_dist, max(1, min(args.steps, 5)), 1)
+        if rank == 0:
+            out["config"]["extra"] = [{
+                "workload": "c3: scenes/bunny (procedural stand-in mesh, 69,312 faces) %dx%d x%dspp depth%d seed%d" %
+                            (r3["H"], r3["W"], w3["spp"], w3["depth"], r3["seed"]),
+                "value": r3["rays_all"] * max(1, min(args.steps, 5)) / r3["dt"] / 1e6, "unit": "Mrays/s",
+                "ms_per_step": r3["dt"] / max(1, min(args.steps, 5)) * 1e3, "kernel_ms": r3["kern_ms"],
+                "rays_per_step": r3["rays_all"],
+                "roofline": roofline(w3, r3["rays_rank"], r3["kern_ms"], r3["bytes_per_ray"], r3["n_simd"]),
+            }]
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.scene, seed)
+            out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -649,12 +649,15 @@ struct Camera {
 // ---------------------------------------------------------------- ray_tracing.cu:12-54
 // TRACE_DEPTH_LIMIT is a compile-time 10 in the reference (ray_tracing.cu:10);
 // BASELINE configs ask for 8 / 50, so it is a run-time parameter here.
+constexpr int kMaxDepthLimit = 64;  // == RTMI_MAX_DEPTH of include/rtmi.h; orc_render clamps to it
 static vec3 Trace(HitableList *world, Ray ray, Xorwow *state, int depth_limit, uint32_t *ray_count) {
+  // Layer storage[TRACE_DEPTH_LIMIT] (ray_tracing.cu:13): a fixed array, as in the reference; only
+  // emitted/attenuation are read back (pos/target/t feed the dead DebugTracePath).
   struct Layer {
     vec3 emitted, attenuation;
   };
-  std::vector<Layer> storage;
-  storage.reserve(depth_limit);
+  Layer storage[kMaxDepthLimit];
+  int n_layers = 0;
   vec3 result;
   for (int depth = 0;; depth++) {
     HitRecord record;
@@ -674,10 +677,10 @@ static vec3 Trace(HitableList *world, Ray ray, Xorwow *state, int depth_limit, u
       result = emitted;
       break;
     }
-    storage.push_back({emitted, attenuation});
+    storage[n_layers++] = {emitted, attenuation};
     ray = reflection;
   }
-  for (int i = (int)storage.size() - 1; i >= 0; i--) result = storage[i].emitted + storage[i].attenuation * result;
+  for (int i = n_layers - 1; i >= 0; i--) result = storage[i].emitted + storage[i].attenuation * result;
   return result;
 }
 
@@ -888,11 +891,12 @@ uint64_t orc_render(orc_scene *s, int height, int width, int spp, int depth_limi
   Scene *sc = S(s);
   if (!pixel_ids) n_pixels = (int64_t)height * width;
   if (n_threads < 1) n_threads = 1;
+  if (depth_limit > kMaxDepthLimit) depth_limit = kMaxDepthLimit;
   std::atomic<int64_t> next(0);
   std::vector<Counters> per(n_threads);
   auto worker = [&](int tid) {
     tl_counters = &per[tid];
-    const int64_t chunk = 64;
+    const int64_t chunk = 8;  // pixels per grab: a 256x256 sample still gives 256 threads 32 grabs each
     for (;;) {
       int64_t b = next.fetch_add(chunk);
       if (b >= n_pixels) break;

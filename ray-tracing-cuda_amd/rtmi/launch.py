@@ -1,0 +1,69 @@
+"""One-process-per-GPU launcher used by bench.py (and testable on CPU with gloo).
+
+The reference starts its ranks with ``mpirun`` and binds ``rank % device_count``
+(/root/reference/scenes/spheres.cu:83-98).  Here the job either runs under
+``python -m torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment) or starts its own ranks: the parent process creates N children with that same
+environment BEFORE it makes any GPU call, waits for them, and returns rank 0's exit code.
+Never falls back to fewer ranks than asked for.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def under_launcher():
+    return "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
+
+def env_rank_world():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def visible_gpus():
+    """Device count without initialising the GPU runtime in this process."""
+    import torch
+    return torch.cuda.device_count()
+
+
+def spawn_ranks(n, script, argv, need_gpus=True, timeout=None):
+    """Start ``n`` ranks of ``script argv`` on this node and wait for them.
+
+    Returns the worst exit code (0 only when every rank exited 0).  Raises SystemExit with a
+    clear message when ``need_gpus`` and fewer than ``n`` GPUs are visible."""
+    if need_gpus:
+        have = visible_gpus()
+        if have < n:
+            raise SystemExit("--gpus %d requested but only %d GPU(s) are visible: refusing to run fewer ranks"
+                             % (n, have))
+    port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    worst = 0
+    try:
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            if rc != 0:
+                worst = worst or rc
+    except subprocess.TimeoutExpired:
+        worst = 124
+    finally:
+        for p in procs:  # exactly the children started here, by PID
+            if p.poll() is None:
+                p.kill()
+    return worst

@@ -1,21 +1,31 @@
 #!/bin/bash
 # Collects the evidence bench.py's numbers are checked against (run on the GPU box):
-#   1. rocprofv3 --kernel-trace --stats of the default bench.py command  -> per-kernel durations
-#   2. separate --pmc passes (SQ instruction mix, FETCH_SIZE, WRITE_SIZE) on a shorter run
-# and writes CSV summaries + one JSON digest under gpurun_out/<tag>/.  Copy what should be
-# judged into profiles/.  Usage: tools/profile_bench.sh <tag> [bench args for pass 1]
+#   1. rocprofv3 --kernel-trace --stats of the default bench.py command -> per-kernel durations
+#      (C2 headline + the C3 line of config.extra);
+#   2. separate --pmc passes (SQ instruction mix twice, FETCH_SIZE, WRITE_SIZE) on ONE launch of
+#      each workload at its full size (c2: cornell 1024^2 x1024 spp d50, c3: bunny 1024^2 x512 spp),
+#      so instruction counts and HBM bytes are per launch of exactly what bench.py times;
+# and writes CSVs + <tag>_summary.json + roofline_inputs.json under gpurun_out/<tag>/.  Copy what
+# should be judged into profiles/ (tools/summarize_profile.py prints the cp commands).
+# Usage: tools/profile_bench.sh <tag> [workloads, default "c2 c3"]
 set -u
 TAG=${1:-prof}; shift || true
+WLS=${*:-c2 c3}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-FULL="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
-SHORT="python3 $ROOT/bench.py --spp 64 --steps 2 --warmup 1 --no-cpu-baseline"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $FULL > $OUT/trace.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $OUT/pmc_sq -- $SHORT > $OUT/pmc_sq.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_sq2 -- $SHORT > $OUT/pmc_sq2.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $SHORT > $OUT/pmc_fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $SHORT > $OUT/pmc_write.log 2>&1 || exit 1
-python3 $ROOT/tools/summarize_profile.py $OUT > $OUT/summary.json
-cat $OUT/summary.json
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_TRANS_F32"
+SQ2="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/trace.log 2>&1 || exit 1
+echo "trace done"
+for WL in $WLS; do
+  ONE="python3 $ROOT/bench.py --workload $WL --steps 1 --warmup 0 --no-cpu-baseline --no-extra"
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ1 --output-format csv -d $OUT/${WL}_pmc_sq -- $ONE > $OUT/${WL}_pmc_sq.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $SQ2 --output-format csv -d $OUT/${WL}_pmc_sq2 -- $ONE > $OUT/${WL}_pmc_sq2.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${WL}_pmc_fetch -- $ONE > $OUT/${WL}_pmc_fetch.log 2>&1 || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${WL}_pmc_write -- $ONE > $OUT/${WL}_pmc_write.log 2>&1 || exit 1
+  echo "$WL pmc done"
+done
+python3 $ROOT/tools/summarize_profile.py $OUT $TAG $WLS > $OUT/${TAG}_summary.json
+cat $OUT/${TAG}_summary.json

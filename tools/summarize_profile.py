@@ -1,17 +1,23 @@
 #!/usr/bin/env python3
-"""Digest of tools/profile_bench.sh output: kernel durations, PMC per launch, HBM traffic."""
+"""Digest of tools/profile_bench.sh output: kernel durations, PMC per launch of the trace kernel,
+HBM traffic, and the instruction-mix inputs bench.py's roofline reads.
+
+usage: summarize_profile.py <out-dir> <tag> <workload> [<workload> ...]
+Prints the digest (JSON) and writes <out-dir>/roofline_inputs.json."""
 import csv
 import glob
 import json
 import os
 import sys
 
-out = sys.argv[1]
+out, tag, wls = sys.argv[1], sys.argv[2], sys.argv[3:]
+SIZES = {"c2": ("cornell_box", "1024x1024x1024_d50"), "c3": ("bunny", "1024x1024x512_d10"),
+         "c4": ("cornell_box", "2048x2048x4096_d50"), "c5": ("birthday", "4096x4096x8192_d10")}
 
 
 def rows(pattern):
     r = []
-    for f in glob.glob(os.path.join(out, pattern)):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
         r += list(csv.DictReader(open(f)))
     return r
 
@@ -26,38 +32,65 @@ def last_json(path):
     return None
 
 
-digest = {}
-stats = [r for r in rows("trace/*/*kernel_stats.csv")]
-digest["kernel_stats"] = [{"name": r["Name"][:60], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
-                           "pct": float(r["Percentage"])} for r in stats[:4]]
+digest = {"tag": tag}
+stats = rows("trace/**/*kernel_stats.csv")
+digest["kernel_stats"] = [{"name": r["Name"][:70], "calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                           "pct": float(r["Percentage"])} for r in stats[:8]]
 digest["bench_full"] = last_json(os.path.join(out, "trace.log"))
-pmc = {}
-for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
-    per = {}
-    for r in rows(d + "/*/*counter_collection.csv"):
-        if "render_kernel" in r["Kernel_Name"]:
-            per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
-    for k, v in per.items():
-        pmc[k] = v[-1]  # last launch of the short run (a timed step)
-    tr = [r for r in rows(d + "/*/*kernel_trace.csv") if "render_kernel" in r["Kernel_Name"]]
-    if tr:
-        pmc.setdefault("_kernel_ms_" + d, (int(tr[-1]["End_Timestamp"]) - int(tr[-1]["Start_Timestamp"])) / 1e6)
-        pmc["_vgpr"], pmc["_sgpr"], pmc["_scratch"], pmc["_lds"] = (tr[-1]["VGPR_Count"], tr[-1]["SGPR_Count"],
-                                                                  tr[-1]["Scratch_Size"], tr[-1]["LDS_Block_Size"])
-digest["pmc_short_run"] = pmc
-short = last_json(os.path.join(out, "pmc_sq.log"))
-if short:
-    rays = short["config"]["rays_per_step"]
-    digest["short_run"] = {"workload": short["config"]["workload"], "rays_per_launch": rays}
-    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
-        # FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 -L).  The gfx950 x2 correction of
-        # MI355X_MICROARCH.md applies to wide coalesced streaming reads only; this kernel's
-        # memory traffic is narrow (dword) so the raw figure is kept and labelled as such.
-        b = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
-        digest["short_run"]["hbm_bytes_per_launch"] = b
-        digest["short_run"]["hbm_bytes_per_ray"] = b / rays
-        digest["short_run"]["algorithmic_bytes_per_ray"] = short["config"]["bytes_per_ray"]
-    if "SQ_INSTS_VALU" in pmc:
-        digest["short_run"]["valu_wave_insts_per_64_rays"] = pmc["SQ_INSTS_VALU"] / (rays / 64.0)
-        digest["short_run"]["salu_wave_insts_per_64_rays"] = pmc["SQ_INSTS_SALU"] / (rays / 64.0)
+inputs = {"note": "instruction mix and HBM bytes of ONE launch of render_kernel per workload, from separate rocprofv3 "
+                  "--pmc passes (tools/profile_bench.sh); bench.py's roofline multiplies the per-64-rays counts by the "
+                  "rays of its own run and divides by its own HIP-event kernel time",
+          "tag": tag, "kernels": {}}
+for wl in wls:
+    scene, key = SIZES[wl]
+    pmc = {}
+    for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+        per = {}
+        for r in rows("%s_%s/**/*counter_collection.csv" % (wl, d)):
+            if "render_kernel" in r["Kernel_Name"]:
+                per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        for k, v in per.items():
+            pmc[k] = v[-1]
+        tr = [r for r in rows("%s_%s/**/*kernel_trace.csv" % (wl, d)) if "render_kernel" in r["Kernel_Name"]]
+        if tr:
+            pmc["_kernel_ms_" + d] = (int(tr[-1]["End_Timestamp"]) - int(tr[-1]["Start_Timestamp"])) / 1e6
+            pmc["_vgpr"], pmc["_sgpr"], pmc["_scratch"], pmc["_lds"] = (tr[-1]["VGPR_Count"], tr[-1]["SGPR_Count"],
+                                                                      tr[-1]["Scratch_Size"], tr[-1]["LDS_Block_Size"])
+    run = last_json(os.path.join(out, "%s_pmc_sq.log" % wl))
+    d = {"pmc": pmc}
+    if run and "SQ_INSTS_VALU" in pmc:
+        rays = run["config"]["rays_per_step"]
+        w64 = rays / 64.0
+        d["workload"] = run["config"]["workload"]
+        d["rays_per_launch"] = rays
+        d["valu_per_64_rays"] = pmc["SQ_INSTS_VALU"] / w64
+        d["trans_per_64_rays"] = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / w64
+        d["salu_per_64_rays"] = pmc["SQ_INSTS_SALU"] / w64
+        n_simd = 1024
+        ms = pmc["_kernel_ms_pmc_sq"]
+        cyc = (2 * pmc["SQ_INSTS_VALU"] + 6 * pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) / n_simd
+        d["valu_issue_frac_of_profiled_launch"] = cyc / (ms * 1e-3 * 2.4e9)
+        if "SQ_WAVE_CYCLES" in pmc and "SQ_BUSY_CYCLES" in pmc:
+            d["waves"] = pmc["SQ_WAVES"]
+        if "SQ_WAIT_ANY" in pmc and "SQ_ACTIVE_INST_ANY" in pmc:
+            tot = pmc["SQ_WAIT_ANY"] + pmc["SQ_WAIT_INST_ANY"] + pmc["SQ_ACTIVE_INST_ANY"]
+            d["wave_time_split"] = {"waiting": pmc["SQ_WAIT_ANY"] / tot, "issue_stalled": pmc["SQ_WAIT_INST_ANY"] / tot,
+                                    "issuing": pmc["SQ_ACTIVE_INST_ANY"] / tot}
+        entry = {"valu_per_64_rays": d["valu_per_64_rays"], "trans_per_64_rays": d["trans_per_64_rays"],
+                 "salu_per_64_rays": d["salu_per_64_rays"], "vgpr": pmc.get("_vgpr"), "sgpr": pmc.get("_sgpr"),
+                 "lds_bytes": pmc.get("_lds"), "profiled_kernel_ms": ms,
+                 "source": "profiles/%s_summary.json (%s)" % (tag, wl), "hbm_bytes_per_launch": {}}
+        if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            # FETCH_SIZE / WRITE_SIZE are in KiB.  The gfx950 x2 correction of MI355X_MICROARCH.md applies to wide
+            # coalesced streaming reads; this kernel's HBM traffic is narrow (dword RNG-state / radiance accesses,
+            # 16-byte gathers for meshes), so the raw figure is kept and labelled as such.
+            b = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
+            d["hbm_bytes_per_launch"] = b
+            d["hbm_fetch_bytes"], d["hbm_write_bytes"] = pmc["FETCH_SIZE"] * 1024.0, pmc["WRITE_SIZE"] * 1024.0
+            entry["hbm_bytes_per_launch"][key] = b
+        inputs["kernels"][scene] = entry
+    digest[wl] = d
+json.dump(inputs, open(os.path.join(out, "roofline_inputs.json"), "w"), indent=1)
+digest["copy"] = ["cp gpurun_out/%s/%s_summary.json profiles/" % (tag, tag),
+                  "cp gpurun_out/%s/roofline_inputs.json profiles/" % tag]
 print(json.dumps(digest, indent=1))
