@@ -50,7 +50,8 @@ typedef enum rtmi_status {
   RTMI_ERR_NO_DEVICE = -2,  /* HIP runtime or device unavailable */
   RTMI_ERR_HIP = -3,        /* a HIP call failed; see rtmi_last_error() */
   RTMI_ERR_CAPACITY = -4,   /* HitableList::kMaxHitables (1024) exceeded, hitable_list.cuh:10 */
-  RTMI_ERR_DEPTH = -5       /* max_depth outside [0, RTMI_MAX_DEPTH] */
+  RTMI_ERR_DEPTH = -5,      /* max_depth outside [0, RTMI_MAX_DEPTH] */
+  RTMI_ERR_INTERNAL = -6    /* an internal invariant of the kernels did not hold; the output is not to be used */
 } rtmi_status;
 
 #define RTMI_MAX_DEPTH 64      /* TRACE_DEPTH_LIMIT is 10 in ray_tracing.cu:10; BASELINE configs use 8/10/50 */
@@ -171,8 +172,13 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 int rtmi_render(const rtmi_scene *s, const rtmi_frame *f, void *d_states, float *d_tiles,
                 uint32_t *d_ray_counts, void *stream);
 /* Total closest-hit queries of the most recent rtmi_render on this scene
- * (waits for `stream`). */
+ * (waits for `stream`).  RTMI_ERR_INTERNAL if that render abandoned a mesh search. */
 int rtmi_last_ray_total(const rtmi_scene *s, uint64_t *out_rays, void *stream);
+/* Diagnostic: the library's raw device counter words of the most recent rtmi_render on this scene
+ * ([0] work-queue head, [1] closest-hit queries, [2] abandoned mesh searches; a -DRTMI_STATS build
+ * of the kernels adds wave-level step counts of the mesh search from word 4 on). */
+#define RTMI_COUNTER_WORDS 32
+int rtmi_debug_counters(const rtmi_scene *s, unsigned long long out[RTMI_COUNTER_WORDS], void *stream);
 
 /* d_all_tiles holds the tile-major buffers of ranks 0..world_size-1 back to
  * back (what an RCCL gather to the root produces; world_size==1: the buffer

@@ -319,7 +319,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->tris, &d.tris))) return rc;
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
-  if ((rc = upload(s, s->subnodes, &d.subnodes))) return rc;
+  if ((rc = upload(s, s->qnodes, &d.qnodes))) return rc;
   if ((rc = upload(s, s->faces, &d.faces))) return rc;
   if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;
@@ -327,7 +327,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.n_runs = (int)s->runs.size();
   d.n_mats = (int)s->mat_recs.size();
   d.n_nodes = (int)s->nodes.size();
-  d.sub_stack = s->sub_depth > 0 ? 3 * s->sub_depth + 1 : 0;
+  d.sub_reserve = s->sub_depth > 0 ? 3 * s->sub_depth + 3 + kMeshFaceSlack : 0;
   d.unsigned_colours = 1;
   for (const MatRec &m : s->mat_recs) {
     const float c[3] = {m.r, m.g, m.b};
@@ -340,9 +340,9 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.cam = s->cam;
   s->dev = d;
   void *c = nullptr;
-  HIP_TRY(hipMalloc(&c, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc(&c, RTMI_COUNTER_WORDS * sizeof(unsigned long long)));
   s->dev_allocs.push_back(c);
-  HIP_TRY(hipMemset(c, 0, 2 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long)));
   s->d_counters = reinterpret_cast<unsigned long long *>(c);
   HIP_TRY(hipDeviceSynchronize());
   s->committed = true;
@@ -515,7 +515,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
     probe.spp = probe_spp;
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
     HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, nullptr, true,
                           blocks, threads, st));
@@ -524,7 +524,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     d_order = p_order;
     d_sparse = p_max + 1;
   }
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, 2 * sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
                         s->d_counters, d_order, d_sparse, false, blocks, threads, st));
   return RTMI_OK;
@@ -534,10 +534,22 @@ int rtmi_last_ray_total(const rtmi_scene *sp, uint64_t *out_rays, void *stream) 
   if (!sp || !out_rays) return fail(RTMI_ERR_INVALID, "null argument");
   const Scene *s = S(sp);
   if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
-  unsigned long long v = 0;
-  HIP_TRY(hipMemcpyAsync(&v, s->d_counters + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  unsigned long long v[2] = {0, 0};  // [0] rays, [1] abandoned mesh searches (must be 0)
+  HIP_TRY(hipMemcpyAsync(v, s->d_counters + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  *out_rays = v;
+  *out_rays = v[0];
+  if (v[1] != 0) return fail(RTMI_ERR_INTERNAL, "mesh search stack overflow: the frame is incomplete");
+  return RTMI_OK;
+}
+
+// Diagnostic: the raw counter words of the most recent render (RTMI_STATS builds fill words 4..16).
+int rtmi_debug_counters(const rtmi_scene *sp, unsigned long long out[RTMI_COUNTER_WORDS], void *stream) {
+  if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  HIP_TRY(hipMemcpyAsync(out, s->d_counters, RTMI_COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                         (hipStream_t)stream));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return RTMI_OK;
 }
 

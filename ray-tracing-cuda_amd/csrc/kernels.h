@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/rtmi.h"  // RTMI_COUNTER_WORDS
 #include "scene_dev.h"
 
 #define RTMI_KERNEL_MAX_DEPTH 64  // == RTMI_MAX_DEPTH of include/rtmi.h

@@ -319,156 +319,286 @@ __device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V
 }
 
 
-// ------------------------------------------------------------------ mesh search helpers
-// Per-lane candidate list in LDS, [slot][word][thread]: word 0 = leaf path code, 1 = face
-// index, 2 (and 3 when t is double) = t.  One entry per reference leaf that holds a hit.
-template <typename T, bool DT>
-__device__ __forceinline__ T hit_list_t(const int *hits, int nthr, int slot) {
-  if (DT) return (T)__hiloint2double(hits[(slot * kHitWords + 3) * nthr], hits[(slot * kHitWords + 2) * nthr]);
-  return (T)__int_as_float(hits[(slot * kHitWords + 2) * nthr]);
+// ------------------------------------------------------------------ mesh search (wave-wide)
+// The search of a mesh's 4-wide tree is done by the WAVE, not by the lane that owns the ray
+// (DESIGN.md "Mesh queries").  What has to be found is every face the triangle test accepts with
+// t_from <= t <= t_to -- no pruning by nearer hits, because the reference's box semantics (quirk g8)
+// make farther hits matter -- so the order in which (ray, node) pairs are looked at is free.  All
+// pending pairs of the wave's 64 rays sit on one stack in LDS; a step pops up to 64 of them, one per
+// lane, whichever ray they belong to.  A wave whose rays need 3, 40 and 0 steps therefore takes
+// ceil(43 / 64) steps per level instead of 40, and a single expensive ray is searched by all 64
+// lanes: its latency is the depth of the tree, not the number of nodes it touches.
+//
+// Stack words: [ray lane : 6][payload : 26]; node entries (payload = node index) grow up from
+// word 0, face-block entries (payload = first face * 8 + count) grow down from the top, so that a
+// step pops entries of one kind.  A node step pops k <= 64 entries and pushes at most 4k; k is
+// chosen so that `reserve` = 3 * depth + 3 + kMeshFaceSlack words stay free afterwards, or 1 when
+// they would not.  Popping one node at a time is a depth-first search: above the level it started
+// from the node end never holds more than 3 * depth entries, and the face end at most 67 (it is
+// drained as soon as it holds 64, and a node adds at most 4), so from a state with `reserve` free
+// words at least 4 stay free and the stack cannot overflow whatever the mesh.  (Should it ever, the
+// search is abandoned and counters[2] reports it: no out-of-range access either way.)
+__device__ __forceinline__ int lane_rank(unsigned long long mask) {  // set bits below my lane
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
-// Record a face that passed the triangle test with parameter t.  Same leaf: the smaller t wins,
-// the higher reference index among equal t (what an in-order scan with `t <= t_to` keeps,
-// bvh.cuh:127-134).  A full list keeps the leaves that come first in visiting order and moves
-// `cut` down to the first leaf it had to leave to the next pass.
-template <typename T, bool DT>
-__device__ __forceinline__ void hit_list_insert(const SceneDev &sc, int *hits, int nthr, int &cnt, int64_t lo_code,
-                                                int64_t &cut, uint32_t code, int face, int orig, float t) {
-  if (!((int64_t)code >= lo_code && (int64_t)code < cut)) return;
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ float ubyte_f32(uint32_t x, int byte) { return (float)((x >> (8 * byte)) & 0xffu); }
+
+// Distance slack of the search boxes.  The binary32 Moller-Trumbore test can accept a ray that
+// misses the exact triangle by about 4e-7 |o - p0| / sin(smallest angle) (the error of
+// dot(tvec, pvec) / det); the padded, outward-quantised boxes cover a fixed margin, and every box is
+// widened by this fraction of (|o|_inf + largest mesh coordinate) >= |o - p0|_inf on top of it.
+#define MESH_DIST_SLACK 0x1p-16f
+
+// Record a face that passed the triangle test with parameter t in its ray's candidate list (`rr` =
+// the ray record).  Same leaf: the smaller t wins, the higher reference index among equal t (what an
+// in-order scan with `t <= t_to` keeps, bvh.cuh:127-134).  A full list keeps the leaves that come
+// first in visiting order and moves `cut` down to the first leaf it had to leave to the next pass.
+__device__ __forceinline__ void hit_list_insert(const SceneDev &sc, int *rr, uint32_t code, int face, int orig,
+                                                float t) {
+  const int cnt = rr[12];
+  const uint32_t cut = (uint32_t)rr[13], lo_code = (uint32_t)rr[14];
+  if (!(code >= lo_code && code < cut)) return;
   int found = -1, jmax = 0;
   uint32_t cmax = 0u;
-  for (int j = 0; j < cnt; j++) {
-    const uint32_t cj = (uint32_t)hits[(j * kHitWords + 0) * nthr];
-    if (cj == code) found = j;
-    if (cj >= cmax) cmax = cj, jmax = j;
+#pragma unroll
+  for (int j = 0; j < kHitSlots; j++) {
+    if (j < cnt) {
+      const uint32_t cj = (uint32_t)rr[16 + j * kHitWords];
+      if (cj == code) found = j;
+      if (cj >= cmax) cmax = cj, jmax = j;
+    }
   }
   int slot = -1;
   if (found >= 0) {
-    const T tj = hit_list_t<T, DT>(hits, nthr, found);
-    bool better = (T)t < tj;
-    if ((T)t == tj) better = orig > sc.faces[hits[(found * kHitWords + 1) * nthr]].orig;
+    const float tj = __int_as_float(rr[16 + found * kHitWords + 2]);
+    bool better = t < tj;
+    if (t == tj) better = orig > sc.faces[rr[16 + found * kHitWords + 1]].orig;
     if (better) slot = found;
   } else if (cnt < kHitSlots) {
-    slot = cnt++;
+    slot = cnt;
+    rr[12] = cnt + 1;
   } else if (code > cmax) {
-    cut = (int64_t)code;  // this leaf and everything after it: next pass
+    rr[13] = (int)code;  // this leaf and everything after it: next pass
   } else {
-    cut = (int64_t)cmax;  // drop the last listed leaf instead
+    rr[13] = (int)cmax;  // drop the last listed leaf instead
     slot = jmax;
   }
   if (slot >= 0) {
-    hits[(slot * kHitWords + 0) * nthr] = (int)code;
-    hits[(slot * kHitWords + 1) * nthr] = face;
+    rr[16 + slot * kHitWords] = (int)code;
+    rr[16 + slot * kHitWords + 1] = face;
+    rr[16 + slot * kHitWords + 2] = __float_as_int(t);
+  }
+}
+
+// Diagnostic build only (-DRTMI_STATS, tools/mesh_stats.sh): wave-level step counts of the search.
+#ifdef RTMI_STATS
+struct MeshStats {
+  unsigned searches, node_steps, face_steps, nodes_popped, blocks_popped, insert_rounds, steps_hist[6];
+  // shader cycles (s_memtime) of this wave: [0] sample bookkeeping + camera ray, [1] world list before the mesh,
+  // [2] mesh search, [3] replay, [4] shading; of the node steps: [5] pop + node/ray fetch, [6] box tests, [7] pushes;
+  // [8] face steps incl. inserts
+  unsigned long long cyc[9];
+};
+__device__ __forceinline__ unsigned long long stat_now() {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define RTMI_STAT(x) x
+#else
+#define RTMI_STAT(x)
+#endif
+
+// One search pass for the lanes with `need`: afterwards every such lane's record holds, per
+// reference leaf with lo_code <= code < cut, the best face with t_from <= t <= bt_to.
+template <typename T, bool DT>
+__device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, float mag, int *wl, bool need, V3 o, V3 d,
+                                            V3 inv_d, T bt_to, uint32_t lo_code, unsigned long long *overflow
+#ifdef RTMI_STATS
+                                            , MeshStats &st
+#endif
+) {
+  const int lane = (int)(threadIdx.x & 63u);
+  RTMI_STAT(st.searches++; unsigned my_steps = 0;)
+  int *stack = wl + 64 * kMeshRayWords;
+  const float lo0 = T_FROM_F * 0.999f;
+  if (need) {
+    int *rr = wl + lane * kMeshRayWords;
+    int w3 = 0, w7 = 0;
     if (DT) {
-      const double td = (double)(T)t;
-      hits[(slot * kHitWords + 2) * nthr] = __double2loint(td);
-      hits[(slot * kHitWords + 3) * nthr] = __double2hiint(td);
+      const double td = (double)bt_to;
+      w3 = __double2loint(td), w7 = __double2hiint(td);
     } else {
-      hits[(slot * kHitWords + 2) * nthr] = __float_as_int(t);
+      w3 = __float_as_int((float)bt_to);
     }
+    *reinterpret_cast<int4 *>(rr + 0) = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), w3);
+    *reinterpret_cast<int4 *>(rr + 4) = make_int4(__float_as_int(d.x), __float_as_int(d.y), __float_as_int(d.z), w7);
+    *reinterpret_cast<int4 *>(rr + 8) = make_int4(__float_as_int(inv_d.x), __float_as_int(inv_d.y), __float_as_int(inv_d.z),
+                                                  __float_as_int((float)bt_to * 1.0001f + 1e-6f));
+    *reinterpret_cast<int4 *>(rr + 12) = make_int4(0, (int)kCodeNone, (int)lo_code, 0);
   }
-}
-__device__ __forceinline__ float lane_bcast(float x, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), lane));
-}
-__device__ __forceinline__ int lane_bcast(int x, int lane) { return __builtin_amdgcn_readlane(x, lane); }
-
-
-// Wave-cooperative finish of a mesh search.  `busy` = the lanes whose search stacks are not
-// empty yet ("owners"), at most 64 / LG of them.  The wave splits into groups of LG lanes, one
-// group per owner; the owner's stack moves to the group's segment of a wave-wide LDS stack and
-// every step pops up to LG / 4 entries per group, 4 lanes per entry -- one child box or one
-// face per lane -- so the owner's chain of dependent steps gets shorter (several entries at
-// once) and cheaper (a quarter of the arithmetic per lane).  Hits go to the owner's list.
-template <typename T, bool DT, int LG>
-__device__ __forceinline__ void coop_finish(const SceneDev &sc, unsigned long long busy, const int *s_substack,
-                                            int *wstack, int *hits, int nthr, int sub_stack, V3 o, V3 d, V3 inv_d,
-                                            float lo0, float hi0, T bt_to, int stop, int &cnt, int64_t lo_code,
-                                            int64_t &cut) {
-  constexpr int kGroups = 64 / LG, kEntries = LG / 4, kSegment = kCoopStack / kGroups;
-  // kEntries per step only while the segment is sure to hold what they can push (4 each) plus
-  // the depth-first remainder of one-entry steps (at most sub_stack - 1 above the switch point);
-  // the caller only picks an LG whose segment holds sub_stack entries
-  const int wide_max = kSegment - 3 * kEntries - (sub_stack - 1);
-  const int lane = (int)(threadIdx.x & 63u), wave_tid0 = (int)(threadIdx.x & ~63u);
-  const int grp = lane / LG, gl = lane % LG, ent = gl >> 2, sub = gl & 3;
-  int owner = -1;
-  {
-    unsigned long long m = busy;
+  const unsigned long long nm = __ballot(need);
+  if (need) stack[lane_rank(nm)] = (lane << 26) | sub_root;
+  int sn = __popcll(nm), sf = 0;
+  const int reserve = sc.sub_reserve;
+  wave_lds_fence();
+  while ((sn | sf) != 0) {
+    if (sf >= 64 || sn == 0) {
+      // ---------------------------------------------------------------- face step
+      const int kf = sf < 64 ? sf : 64;
+      RTMI_STAT(st.face_steps++; st.blocks_popped += kf; my_steps++; const unsigned long long tf0 = stat_now();)
+      const bool mine = lane < kf;
+      int e = 0;
+      if (mine) e = stack[kMeshStackWords - sf + lane];
+      sf -= kf;
+      wave_lds_fence();
+      unsigned pend = 0u;  // bit j: face first + j passed the test ...
+      float pt0 = 0.f, pt1 = 0.f, pt2 = 0.f, pt3 = 0.f;  // ... with this t
+      const int owner = (int)((unsigned)e >> 26), fcnt = e & 7, first = (e >> 3) & (kMeshMaxFaces - 1);
+      int *rr = wl + owner * kMeshRayWords;
+      if (mine) {
+        const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r1 = *reinterpret_cast<const float4 *>(rr + 4);
+        T t_to;
+        if (DT) {
+          t_to = (T)__hiloint2double(__float_as_int(r1.w), __float_as_int(r0.w));
+        } else {
+          t_to = (T)r0.w;
+        }
+        const V3 ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
+        const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + first);
 #pragma unroll
-    for (int k = 0; k < kGroups; k++) {
-      if (m != 0ull) {
-        if (grp == k) owner = __builtin_ctzll(m);
-        m &= m - 1ull;
-      }
-    }
-  }
-  const int src = owner >= 0 ? owner : lane;
-  const V3 ro = mk(__shfl(o.x, src), __shfl(o.y, src), __shfl(o.z, src));
-  const V3 rd = mk(__shfl(d.x, src), __shfl(d.y, src), __shfl(d.z, src));
-  const V3 rinv = mk(__shfl(inv_d.x, src), __shfl(inv_d.y, src), __shfl(inv_d.z, src));
-  const float rhi0 = __shfl(hi0, src);
-  T rt_to;
-  if (DT) {
-    rt_to = (T)__shfl((double)bt_to, src);
-  } else {
-    rt_to = (T)__shfl((float)bt_to, src);
-  }
-  int size = __shfl(stop, src);
-  if (owner < 0) size = 0;
-  int *wseg = wstack + grp * kSegment;
-  for (int k = gl; k < size; k += LG) wseg[k] = s_substack[(size_t)k * nthr + wave_tid0 + owner];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  while (__ballot(size > 0) != 0ull) {
-    const int want = (kEntries > 1 && size <= wide_max) ? kEntries : 1;
-    const int width = size < want ? size : want;
-    const bool mine = ent < width;
-    int e = 0;
-    if (mine) e = wseg[size - 1 - ent];
-    size -= width;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    bool push = false, fhit = false;
-    int child = -1, face = 0, orig = 0;
-    uint32_t code = 0u;
-    float ft = 0.f;
-    if (mine) {
-      if (e >= 0) {
-        const float *nb = reinterpret_cast<const float *>(sc.subnodes + e);
-        BvhNode bx;
-        bx.mn[0] = nb[sub], bx.mn[1] = nb[4 + sub], bx.mn[2] = nb[8 + sub];
-        bx.mx[0] = nb[12 + sub], bx.mx[1] = nb[16 + sub], bx.mx[2] = nb[20 + sub];
-        child = __float_as_int(nb[24 + sub]);
-        push = child != -1 && slab_touch(bx, 0.f, ro, rinv, lo0, rhi0);
-      } else {
-        const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
-        if (sub < fcnt) {
-          face = first + sub;
-          const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + face);
-          const float4 a = fp4[0], b = fp4[1], c = fp4[2];
-          float u = 0.f, v = 0.f;
-          fhit = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), ro, rd, rt_to, ft, u, v);
-          orig = __float_as_int(c.y);
-          code = (uint32_t)__float_as_int(c.z);
+        for (int half = 0; half < 2; half++) {
+          if (half * 2 < fcnt) {
+            float4 q[6];
+#pragma unroll
+            for (int w = 0; w < 6; w++) q[w] = fp4[half * 6 + w];  // `faces` carries 4 records of padding
+#pragma unroll
+            for (int fi = 0; fi < 2; fi++) {
+              if (half * 2 + fi < fcnt) {
+                const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
+                float t = 0.f, u = 0.f, v = 0.f;
+                bool th = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), ro, rd, t_to, t, u, v);
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 2
+                th = th && t < -1.f;  // never
+#endif
+                if (th) {
+                  pend |= 1u << (half * 2 + fi);
+                  if (half * 2 + fi == 0) pt0 = t;
+                  if (half * 2 + fi == 1) pt1 = t;
+                  if (half * 2 + fi == 2) pt2 = t;
+                  if (half * 2 + fi == 3) pt3 = t;
+                }
+              }
+            }
+          }
         }
       }
-    }
-    const unsigned long long pm = __ballot(push);
-    const uint32_t pg = (uint32_t)(pm >> (grp * LG)) & ((1u << LG) - 1u);  // my group's pushes
-    if (push) wseg[size + __popc(pg & ((1u << gl) - 1u))] = child;
-    size += __popc(pg);
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (unsigned long long hm = __ballot(fhit); hm != 0ull; hm &= hm - 1ull) {
-      const int l = __builtin_ctzll(hm);
-      const int to = lane_bcast(owner, l);
-      const uint32_t hcode = (uint32_t)lane_bcast((int)code, l);
-      const int hface = lane_bcast(face, l), horig = lane_bcast(orig, l);
-      const float ht = lane_bcast(ft, l);
-      if (lane == to) hit_list_insert<T, DT>(sc, hits, nthr, cnt, lo_code, cut, hcode, hface, horig, ht);
+      // hits go to their ray's list; two lanes with hits for the same ray take turns
+      while (__ballot(pend != 0u) != 0ull) {
+        RTMI_STAT(st.insert_rounds++;)
+        const bool has = pend != 0u;
+        if (has) rr[15] = lane;
+        wave_lds_fence();
+        if (has && rr[15] == lane) {
+          const int j = __builtin_ctz(pend);
+          const float t = j == 0 ? pt0 : j == 1 ? pt1 : j == 2 ? pt2 : pt3;
+          const FaceRec *f = sc.faces + (first + j);
+          hit_list_insert(sc, rr, f->code, first + j, f->orig, t);
+          pend &= pend - 1u;
+        }
+        wave_lds_fence();
+      }
+      RTMI_STAT(st.cyc[8] += stat_now() - tf0;)
+    } else {
+      // ---------------------------------------------------------------- node step
+      int k = (kMeshStackWords - sn - sf - reserve) / 3;
+      k = k < 1 ? 1 : k;
+      k = k > 64 ? 64 : k;
+      k = k > sn ? sn : k;
+      if (3 * k > kMeshStackWords - sn - sf) {  // cannot happen (see above); never write out of range
+        if (lane == 0) atomicAdd(overflow, 1ull);
+        break;
+      }
+      RTMI_STAT(st.node_steps++; st.nodes_popped += k; my_steps++; const unsigned long long tn0 = stat_now(); unsigned long long tn1 = tn0;)
+      const bool mine = lane < k;
+      int e = 0;
+      if (mine) e = stack[sn - 1 - lane];
+      sn -= k;
+      wave_lds_fence();
+      bool h0 = false, h1 = false, h2 = false, h3 = false;
+      int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+      const uint32_t owner_bits = (uint32_t)e & 0xfc000000u;
+      if (mine) {
+        const int owner = (int)((unsigned)e >> 26), idx = e & (kMeshMaxNodes - 1);
+        const uint4 *np = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
+        const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+        const int *rr = wl + owner * kMeshRayWords;
+        const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r2 = *reinterpret_cast<const float4 *>(rr + 8);
+        const float hi0 = r2.w;
+        RTMI_STAT(tn1 = stat_now();)
+        // the ray in the node's grid: q-coordinate of the origin and time per grid step, per axis
+        const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(r0.x), fabsf(r0.y)), fabsf(r0.z)) + mag);
+        const float oo[3] = {r0.x, r0.y, r0.z}, ii[3] = {r2.x, r2.y, r2.z};
+        const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+        const uint32_t qlo[3] = {w1.x, w1.y, w1.z}, qhi[3] = {w1.w, w2.x, w2.y};
+        float ka[3], kb[3], idq[3];  // t_lo = qlo * idq + ka, t_hi = qhi * idq + kb
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const int ex = (int)(int8_t)((w0.w >> (8 * a)) & 0xffu);
+          const float oq = ldexpf(oo[a] - org[a], -ex);
+          const float rho = ldexpf(delta, -ex);
+          // finite even for a clamped reciprocal on a coarse grid: |q - oq| >= rho > 0 keeps the
+          // product away from 0 * inf, and med3 keeps it below infinity
+          idq[a] = __builtin_amdgcn_fmed3f(ldexpf(ii[a], ex), -1e35f, 1e35f);
+          ka[a] = -(oq + rho) * idq[a];
+          kb[a] = -(oq - rho) * idq[a];
+        }
+        const int cch[4] = {(int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
+        bool hh[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float en = -INFINITY, le = INFINITY;
+#pragma unroll
+          for (int a = 0; a < 3; a++) {
+            const float tl = __builtin_fmaf(ubyte_f32(qlo[a], c), idq[a], ka[a]);
+            const float th = __builtin_fmaf(ubyte_f32(qhi[a], c), idq[a], kb[a]);
+            en = fmaxf(en, fminf(tl, th));
+            le = fminf(le, fmaxf(tl, th));
+          }
+          const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), 1e-5f, en));
+          const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), 1e-5f, le));
+          hh[c] = cch[c] != -1 && lo <= hi;
+        }
+        h0 = hh[0], h1 = hh[1], h2 = hh[2], h3 = hh[3];
+        c0 = cch[0], c1 = cch[1], c2 = cch[2], c3 = cch[3];
+      }
+      RTMI_STAT(const unsigned long long tn2 = stat_now(); st.cyc[5] += tn1 - tn0; st.cyc[6] += tn2 - tn1;)
+      // children that were touched: nodes onto the node end, face blocks onto the face end
+#define RTMI_PUSH_CHILD(H, C)                                                           \
+  {                                                                                     \
+    const bool pn = (H) && (C) >= 0, pf = (H) && (C) < 0;                               \
+    const unsigned long long mn_ = __ballot(pn), mf_ = __ballot(pf);                    \
+    if (pn) stack[sn + lane_rank(mn_)] = (int)(owner_bits | (uint32_t)(C));             \
+    if (pf) stack[kMeshStackWords - 1 - sf - lane_rank(mf_)] = (int)(owner_bits | (uint32_t)(-((C) + 1))); \
+    sn += __popcll(mn_);                                                                \
+    sf += __popcll(mf_);                                                                \
+  }
+      RTMI_PUSH_CHILD(h0, c0)
+      RTMI_PUSH_CHILD(h1, c1)
+      RTMI_PUSH_CHILD(h2, c2)
+      RTMI_PUSH_CHILD(h3, c3)
+#undef RTMI_PUSH_CHILD
+      wave_lds_fence();
+      RTMI_STAT(st.cyc[7] += stat_now() - tn2;)
     }
   }
+  RTMI_STAT(st.steps_hist[my_steps <= 1 ? 0 : my_steps <= 4 ? 1 : my_steps <= 8 ? 2 : my_steps <= 12 ? 3 : my_steps <= 20 ? 4 : 5]++;)
 }
 
 struct Hit {
@@ -487,8 +617,12 @@ struct Hit {
 // lanes); a lane that is not tracing passes live = false and gets an unused result.  The other
 // variants are only entered by tracing lanes and pass true.
 template <uint32_t F>
-__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes,
-                                           int *s_substack, int coop_lanes, V3 o, V3 d, bool live) {
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, int *wl,
+                                           unsigned long long *overflow, V3 o, V3 d, bool live
+#ifdef RTMI_STATS
+                                           , MeshStats &st
+#endif
+) {
   constexpr bool DT = (F & F_SPHERE) != 0;
   typedef typename TSel<DT>::type T;
   bool ok = false;
@@ -613,7 +747,11 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         win = acc ? make_id(RUN_SPHERE, run.first + i) : win;
       }
     }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 3
+    if (false) {
+#else
     if ((F & F_BVH) && run.kind == RUN_BVH) {
+#endif
       // BVH::Hit (bvh.cuh:123-183) answered without walking the reference's tree.
       //
       // What the reference computes: a depth-first walk, left subtree first, with a running
@@ -627,16 +765,14 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       //  * leaves without a hit change nothing; whether their boxes were entered is irrelevant;
       //  * a box test is only ever needed on the root-to-leaf path of a leaf that holds a hit,
       //    and it sees the t_to left by the hit leaves before it in visiting order.
-      // So: (1) one search of the mesh-wide 4-wide tree collects, per reference leaf, the best
-      // face (a small per-lane list keyed by the leaf's path code); (2) the listed leaves are
-      // replayed in visiting order, evaluating the reference's exact box test on the path nodes
-      // not shared with the previously replayed leaf.  If more leaves hold hits than the list
-      // has slots, the leaves beyond `cut` are left to a further search pass.
+      // So: (1) one search of the mesh-wide 4-wide tree (mesh_search: by the whole wave, for all
+      // its rays at once) collects, per reference leaf, the best face in the ray's small list
+      // keyed by the leaf's path code; (2) each lane replays its listed leaves in visiting order,
+      // evaluating the reference's exact box test on the path nodes not shared with the previously
+      // replayed leaf.  If more leaves hold hits than the list has slots, the leaves beyond `cut`
+      // are left to a further search pass.
       const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
-      const int nthr = blockDim.x;
-      int *sstack = s_substack + threadIdx.x;                                // [level][thread]
-      int *hits = s_substack + (size_t)sc.sub_stack * nthr + threadIdx.x;    // [slot][word][thread]
-      int *wstack = s_substack + (size_t)(sc.sub_stack + kHitListWords) * nthr + (size_t)(threadIdx.x >> 6) * kCoopStack;
+      int *rr = wl + (int)(threadIdx.x & 63u) * kMeshRayWords;
       for (int i = 0; i < run.count; i++) {
         const BvhRec br = sc.bvhs[run.first + i];
         T bt_to = t_to;
@@ -647,143 +783,87 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         // one bit per level "that node of its path was entered"
         bool have_prev = false;
         uint32_t prev_code = 0u, entered = 0u;
-        int64_t lo_code = 0, cut = (int64_t)1 << 32;
+        uint32_t lo_code = 0u;
         bool need = live;
-        // All 64 lanes walk this loop together (dead lanes with need == false): the tail of a
-        // search is finished by the whole wave on behalf of the few lanes still at it.
+        // All 64 lanes walk this loop together (lanes without a ray with need == false): the search
+        // is the wave's.
         while (__ballot(need) != 0ull) {
           // ---- (1) search: best face per leaf with lo_code <= code < cut, t <= bt_to
-          int cnt = 0;
-          int stop = 0;
-          if (need) sstack[(stop++) * nthr] = br.sub_root;
-          const float lo0 = T_FROM_F * 0.999f, hi0 = (float)bt_to * 1.0001f + 1e-6f;
-          for (;;) {
-            const unsigned long long busy = __ballot(stop > 0);
-            if (busy == 0ull) break;
-            if (__popcll(busy) <= coop_lanes) {
-              // ---- wave-cooperative finish (see coop_finish): the fewer lanes are left, the
-              // more lanes work for each of them
-              const int left = __popcll(busy);
-              if (left <= 4)
-                coop_finish<T, DT, 16>(sc, busy, s_substack, wstack, hits, nthr, sc.sub_stack, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
-                                       lo_code, cut);
-              else if (left <= 8)
-                coop_finish<T, DT, 8>(sc, busy, s_substack, wstack, hits, nthr, sc.sub_stack, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
-                                      lo_code, cut);
-              else
-                coop_finish<T, DT, 4>(sc, busy, s_substack, wstack, hits, nthr, sc.sub_stack, o, d, inv_d, lo0, hi0, bt_to, stop, cnt,
-                                      lo_code, cut);
-              stop = 0;
-              break;
-            }
-            if (stop > 0) {
-              // ---- per-lane step.  An entry is a 4-wide node (>= 0; 128 B) or a range of up
-              // to four faces (< 0; 4 x 48 B, `faces` carries 4 records of padding).  Lanes of a
-              // wave rarely agree on which, so both kinds are fetched by the same eight 16-byte
-              // loads (plus four more on face lanes) BEFORE the kind is branched on: one memory
-              // round trip per step, not one per side of the branch.
-              const int e = sstack[(--stop) * nthr];
-              const bool is_node = e >= 0;
-              const int enc = -(e + 1), fcnt = enc & 7, first = enc >> 3;
-              const float4 *base = is_node ? reinterpret_cast<const float4 *>(sc.subnodes + e)
-                                           : reinterpret_cast<const float4 *>(sc.faces + first);
-              float4 q[12];
-#pragma unroll
-              for (int w = 0; w < 8; w++) q[w] = base[w];
-              if (!is_node) {
-#pragma unroll
-                for (int w = 8; w < 12; w++) q[w] = base[w];
-              }
-              if (is_node) {
-                // four padded child boxes (plane-major) + four child references
-                const float4 mnx = q[0], mny = q[1], mnz = q[2], mxx = q[3], mxy = q[4], mxz = q[5];
-                const float4 chf = q[6];
-                const float cmnx[4] = {mnx.x, mnx.y, mnx.z, mnx.w}, cmny[4] = {mny.x, mny.y, mny.z, mny.w},
-                            cmnz[4] = {mnz.x, mnz.y, mnz.z, mnz.w}, cmxx[4] = {mxx.x, mxx.y, mxx.z, mxx.w},
-                            cmxy[4] = {mxy.x, mxy.y, mxy.z, mxy.w}, cmxz[4] = {mxz.x, mxz.y, mxz.z, mxz.w};
-                const int cch[4] = {__float_as_int(chf.x), __float_as_int(chf.y), __float_as_int(chf.z),
-                                    __float_as_int(chf.w)};
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                  BvhNode bx;
-                  bx.mn[0] = cmnx[c], bx.mn[1] = cmny[c], bx.mn[2] = cmnz[c];
-                  bx.mx[0] = cmxx[c], bx.mx[1] = cmxy[c], bx.mx[2] = cmxz[c];
-                  // an unused slot has mn = +inf, mx = -inf and fails the test
-                  if (cch[c] != -1 && slab_touch(bx, 0.f, o, inv_d, lo0, hi0)) sstack[(stop++) * nthr] = cch[c];
-                }
-              } else {
-#pragma unroll
-                for (int fi = 0; fi < 4; fi++) {
-                  if (fi < fcnt) {
-                    const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
-                    float t = 0.f, u = 0.f, v = 0.f;
-                    if (tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, bt_to, t, u, v))
-                      hit_list_insert<T, DT>(sc, hits, nthr, cnt, lo_code, cut, (uint32_t)__float_as_int(c.z), first + fi,
-                                             __float_as_int(c.y), t);
-                  }
-                }
-              }
-            }
-          }
+          RTMI_STAT(const unsigned long long ts0 = stat_now();)
+          mesh_search<T, DT>(sc, br.sub_root, br.mag, wl, need, o, d, inv_d, bt_to, lo_code, overflow
+#ifdef RTMI_STATS
+                             , st
+#endif
+          );
+          RTMI_STAT(const unsigned long long ts1 = stat_now(); st.cyc[2] += ts1 - ts0;)
           // ---- (2) replay the listed leaves in the reference's visiting order
-          int64_t last = -1;
-          for (int k = 0; k < cnt; k++) {
-            int sel = -1;
-            uint32_t code = 0xffffffffu;
-            for (int j = 0; j < cnt; j++) {
-              const uint32_t cj = (uint32_t)hits[(j * kHitWords + 0) * nthr];
-              if ((int64_t)cj > last && (int64_t)cj < cut && cj <= code) code = cj, sel = j;
-            }
-            if (sel < 0) break;  // the rest was pushed beyond `cut`
-            last = (int64_t)code;
-            const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
-            uint32_t bits = shared ? entered & (0xffffffffu << (32 - shared)) : 0u;
-            int ni = br.root;
-            bool ent = true;
-            for (int lvl = 1;; lvl++) {
-              int left, right;
-              if (ni < lds_nodes) {
-                left = s_nodes[ni].left, right = s_nodes[ni].right;
-              } else {
-                left = sc.nodes[ni].left, right = sc.nodes[ni].right;
-              }
-              if (right < 0) break;  // ni is the leaf, and every box on the way was entered
-              const uint32_t bit = 0x80000000u >> (lvl - 1);
-              ni = (code & bit) ? right : left;
-              if (lvl <= shared) {
-                ent = (bits & bit) != 0u;
-              } else {
-                BvhNode nd;
-                if (ni < lds_nodes) {
-                  nd = s_nodes[ni];
-                } else {
-                  nd = sc.nodes[ni];
+          uint32_t cut = kCodeNone;
+          if (need) {
+            const int cnt = rr[12];
+            cut = (uint32_t)rr[13];
+            bool have_last = false;
+            uint32_t last = 0u;
+            for (int k = 0; k < cnt; k++) {
+              int sel = -1;
+              uint32_t code = 0xffffffffu;
+#pragma unroll
+              for (int j = 0; j < kHitSlots; j++) {
+                if (j < cnt) {
+                  const uint32_t cj = (uint32_t)rr[16 + j * kHitWords];
+                  if ((!have_last || cj > last) && cj < cut && cj <= code) code = cj, sel = j;
                 }
-                ent = aabb_test<T>(nd, o, d, bt_to);
-                if (ent) bits |= bit;
               }
-              if (!ent) break;
-            }
-            have_prev = true;
-            prev_code = code;
-            entered = bits;
-            if (ent) {
-              T tj;
-              if (DT) {
-                tj = (T)__hiloint2double(hits[(sel * kHitWords + 3) * nthr], hits[(sel * kHitWords + 2) * nthr]);
-              } else {
-                tj = (T)__int_as_float(hits[(sel * kHitWords + 2) * nthr]);
+              if (sel < 0) break;  // the rest was pushed beyond `cut`
+              have_last = true;
+              last = code;
+              const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
+              uint32_t bits = shared ? entered & (0xffffffffu << (32 - shared)) : 0u;
+              int ni = br.root;
+              bool ent = true;
+              for (int lvl = 1;; lvl++) {
+                int left, right;
+                if (ni < lds_nodes) {
+                  left = s_nodes[ni].left, right = s_nodes[ni].right;
+                } else {
+                  left = sc.nodes[ni].left, right = sc.nodes[ni].right;
+                }
+                if (right < 0) break;  // ni is the leaf, and every box on the way was entered
+                const uint32_t bit = 0x80000000u >> (lvl - 1);
+                ni = (code & bit) ? right : left;
+                if (lvl <= shared) {
+                  ent = (bits & bit) != 0u;
+                } else {
+                  BvhNode nd;
+                  if (ni < lds_nodes) {
+                    nd = s_nodes[ni];
+                  } else {
+                    nd = sc.nodes[ni];
+                  }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 1
+                  ent = true;
+#else
+                  ent = aabb_test<T>(nd, o, d, bt_to);
+#endif
+                  if (ent) bits |= bit;
+                }
+                if (!ent) break;
               }
-              if (tj <= bt_to) {
-                bt_to = tj;
-                bhit = true;
-                bface = hits[(sel * kHitWords + 1) * nthr];
+              have_prev = true;
+              prev_code = code;
+              entered = bits;
+              if (ent) {
+                const T tj = (T)__int_as_float(rr[16 + sel * kHitWords + 2]);
+                if (tj <= bt_to) {
+                  bt_to = tj;
+                  bhit = true;
+                  bface = rr[16 + sel * kHitWords + 1];
+                }
               }
             }
           }
-          need = need && !(cut >> 32);  // leaves were deferred: search again from `cut` on
+          need = need && cut != kCodeNone;  // leaves were deferred: search again from `cut` on
           lo_code = cut;
-          cut = (int64_t)1 << 32;
+          RTMI_STAT(st.cyc[3] += stat_now() - ts1;)
         }
         if (bhit && (F & F_TEX)) {
           // barycentrics of the winner (the same binary32 operations as in the search)
@@ -823,9 +903,8 @@ struct LaunchCfg {
   int32_t stack_off;   // byte offset of the id stack inside dynamic LDS
   int32_t nodes_off;   // byte offset of the staged reference-tree nodes
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
-  int32_t substack_off;  // byte offset of the per-lane sub-tree stacks (BVH variants)
-  int32_t coop_lanes;  // mesh search: the wave finishes together once at most this many lanes still search
-  int32_t pad;
+  int32_t mesh_off;    // byte offset of the per-wave mesh-search regions (kMeshWaveWords words each; BVH variants)
+  int32_t pad[2];
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two; kSparseStride unless RTMI_SPARSE_STRIDE overrides it
@@ -845,6 +924,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << ids_shift);
   };
   const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
+  int *wl = nullptr;  // this wave's mesh-search region
+  if (F & F_BVH)
+    wl = reinterpret_cast<int *>(smem + lc.mesh_off) +
+         __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kMeshWaveWords;
   const bool mats_in_lds = lc.lds_mats > 0;
   const bool fast_fold = mats_in_lds && !lc.wide_ids && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
@@ -890,7 +973,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   unsigned long long sparse_limit = 0ull;
   if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
 
+  RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_now();)
   for (;;) {
+    RTMI_STAT(const unsigned long long tq0 = stat_now();)
     // -------------------------------------------------------- sample / pixel bookkeeping
     if (!active && !done) {
       if (has_px && k >= fr.spp) {
@@ -980,12 +1065,23 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       continue;  // lanes held back from the sparse head of the queue: it has just moved on
     }
 
+    RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
+              const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
     Hit h = {};
     if (F & F_BVH)  // every lane goes in: see closest_hit
-      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, reinterpret_cast<int *>(smem + lc.substack_off), lc.coop_lanes, o, d,
-                         active);
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, wl, counters + 2, o, d, active
+#ifdef RTMI_STATS
+                         , st
+#endif
+      );
+    RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
     if (active) {
-      if (!(F & F_BVH)) h = closest_hit<F>(sc, s_nodes, 0, reinterpret_cast<int *>(smem + lc.substack_off), 0, o, d, true);
+      if (!(F & F_BVH))
+        h = closest_hit<F>(sc, s_nodes, 0, nullptr, nullptr, o, d, true
+#ifdef RTMI_STATS
+                           , st
+#endif
+        );
       rays++;
 
       V3 result = splat(0.f);
@@ -1159,11 +1255,25 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         active = false;
       }
     }
+    RTMI_STAT(st.cyc[4] += stat_now() - tq2;)
   }
 
   // total closest-hit queries: wave reduce, one atomic per wave
   for (int off = 32; off > 0; off >>= 1) ray_total += __shfl_down(ray_total, off);
   if ((threadIdx.x & 63) == 0 && ray_total) atomicAdd(&counters[1], ray_total);
+#ifdef RTMI_STATS
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned v[13] = {wave_queries, st.searches, st.node_steps, st.face_steps, st.nodes_popped, st.blocks_popped,
+                            st.insert_rounds, st.steps_hist[0], st.steps_hist[1], st.steps_hist[2], st.steps_hist[3],
+                            st.steps_hist[4], st.steps_hist[5]};
+    for (int i = 0; i < 13; i++) atomicAdd(&counters[4 + i], (unsigned long long)v[i]);
+    for (int i = 0; i < 9; i++) atomicAdd(&counters[17 + i], st.cyc[i]);
+    const unsigned long long life = stat_now() - t_begin;
+    atomicAdd(&counters[26], life);
+    atomicMax(&counters[27], life);
+    atomicAdd(&counters[28], 1ull);
+  }
+#endif
 }
 
 // The trace kernel proper, and the same code under a second name for the scheduler's 2-spp
@@ -1345,15 +1455,6 @@ int sparse_stride() {
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
   LaunchCfg lc{};
   lc.tile_order = nullptr;
-  {
-    const char *e = getenv("RTMI_COOP_LANES");  // tuning knob
-    lc.coop_lanes = e ? atoi(e) : kCoopLanes;
-    if (lc.coop_lanes > kCoopLanes) lc.coop_lanes = kCoopLanes;  // one group of >= 4 lanes per finishing search
-    // ... whose segment of the wave-wide stack (kCoopStack / groups words) must hold a whole per-lane stack
-    while (lc.coop_lanes > 0 && kCoopStack / (lc.coop_lanes > 8 ? 16 : lc.coop_lanes > 4 ? 8 : 4) < sc.sub_stack)
-      lc.coop_lanes = lc.coop_lanes > 8 ? 8 : lc.coop_lanes > 4 ? 4 : 0;
-    if (lc.coop_lanes < 0) lc.coop_lanes = 0;
-  }
   lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
   lc.wide_ids = sc.n_mats > 256 ? 1 : 0;
   size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
@@ -1362,9 +1463,9 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t noff = (off + stack + 15) & ~(size_t)15;
   lc.nodes_off = (int32_t)noff;
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
-  size_t soff = noff + (size_t)lc.lds_nodes * sizeof(BvhNode);
-  lc.substack_off = (int32_t)soff;
-  *lds_bytes = soff + ((variant & F_BVH) ? ((size_t)(sc.sub_stack + kHitListWords) * threads + (size_t)(threads / 64) * kCoopStack) * sizeof(int) : 0);
+  size_t soff = (noff + (size_t)lc.lds_nodes * sizeof(BvhNode) + 15) & ~(size_t)15;
+  lc.mesh_off = (int32_t)soff;
+  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
   return lc;
 }
 

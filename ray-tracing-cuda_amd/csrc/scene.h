@@ -63,15 +63,15 @@ struct Scene {
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;
   std::vector<BvhNode> nodes;
-  std::vector<SubNode4> subnodes;
-  int sub_depth = 0;  // deepest sub-tree (levels of SubNode4)
+  std::vector<QNode4> qnodes;
+  int sub_depth = 0;  // deepest search tree (levels of QNode4)
   std::vector<FaceRec> faces;
   std::vector<float> face_uv;
   std::vector<MatRec> mat_recs;
   std::vector<TexRec> tex_recs;
   std::vector<void *> dev_allocs;
   SceneDev dev{};
-  unsigned long long *d_counters = nullptr;  // [0] work queue head, [1] total rays
+  unsigned long long *d_counters = nullptr;  // [0] work queue head, [1] total rays, [2] abandoned mesh searches
   int device = -1;
   int64_t bytes_per_ray = 0;
   // scratch of the longest-first scheduler (probe states, probe ray counts, costs, order)

@@ -124,97 +124,216 @@ struct FacePts {
   uint32_t code;
 };
 
-// Padded bounds of faces [first, first+n): no face the binary32 Moller-Trumbore test can accept
-// is ever culled by the (also slack) slab test of the kernel.
-static void padded_bounds(const std::vector<FacePts> &fp, int first, int n, float mn[3], float mx[3]) {
-  for (int k = 0; k < 3; k++) mn[k] = INFINITY, mx[k] = -INFINITY;
-  for (int i = 0; i < n; i++)
+// ---- the search tree (DESIGN.md "Mesh queries"): binned-SAH binary tree over the faces, leaves
+// of <= 4 faces, collapsed to four children per node and quantised into QNode4 records.  Which
+// leaf of the REFERENCE's tree a face sits in is carried by the face (FaceRec::code), not by this
+// tree, so the splits are free to follow the geometry.
+struct BinNode {
+  float mn[3], mx[3];  // exact bounds of the faces below
+  int left = -1, right = -1;
+  int first = 0, n = 0;
+};
+
+static inline float face_centroid(const FacePts &f, int a) {
+  const float c[3] = {f.p[0].x + f.p[1].x + f.p[2].x, f.p[0].y + f.p[1].y + f.p[2].y, f.p[0].z + f.p[1].z + f.p[2].z};
+  return c[a];
+}
+static inline double half_area(const float mn[3], const float mx[3]) {
+  const double dx = (double)mx[0] - mn[0], dy = (double)mx[1] - mn[1], dz = (double)mx[2] - mn[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+// Faces [first, first+n) are reordered in place.  Binned surface-area heuristic (16 bins per axis
+// on the centroid bounds); a median split along the longest centroid axis when no bin boundary
+// separates the faces, and below `balanced_below` levels (which bounds the depth on adversarial
+// inputs: coincident or geometrically nested faces).
+static int build_bin(std::vector<BinNode> &bn, std::vector<FacePts> &fp, int first, int n, int level) {
+  BinNode nd;
+  float cmn[3], cmx[3];
+  for (int k = 0; k < 3; k++) nd.mn[k] = cmn[k] = INFINITY, nd.mx[k] = cmx[k] = -INFINITY;
+  for (int i = 0; i < n; i++) {
+    const FacePts &f = fp[first + i];
     for (int j = 0; j < 3; j++) {
-      const V3 &p = fp[first + i].p[j];
-      const float q[3] = {p.x, p.y, p.z};
-      for (int k = 0; k < 3; k++) mn[k] = fminf(mn[k], q[k]), mx[k] = fmaxf(mx[k], q[k]);
+      const float q[3] = {f.p[j].x, f.p[j].y, f.p[j].z};
+      for (int k = 0; k < 3; k++) nd.mn[k] = fminf(nd.mn[k], q[k]), nd.mx[k] = fmaxf(nd.mx[k], q[k]);
     }
+    for (int k = 0; k < 3; k++) {
+      const float c = face_centroid(f, k);
+      cmn[k] = fminf(cmn[k], c), cmx[k] = fmaxf(cmx[k], c);
+    }
+  }
+  nd.first = first, nd.n = n;
+  const int me = (int)bn.size();
+  bn.push_back(nd);
+  if (n <= 4) return me;
+  constexpr int NB = 16;
+  constexpr int balanced_below = 40;
+  int mid = -1;
+  if (level < balanced_below) {
+    double best = INFINITY;
+    int best_axis = -1, best_bin = -1;
+    for (int a = 0; a < 3; a++) {
+      const float lo = cmn[a], hi = cmx[a];
+      if (!(hi > lo)) continue;
+      const float scale = (float)NB / (hi - lo);
+      float bmn[NB][3], bmx[NB][3];
+      int cnt[NB];
+      for (int b = 0; b < NB; b++) {
+        cnt[b] = 0;
+        for (int k = 0; k < 3; k++) bmn[b][k] = INFINITY, bmx[b][k] = -INFINITY;
+      }
+      for (int i = 0; i < n; i++) {
+        const FacePts &f = fp[first + i];
+        int b = (int)((face_centroid(f, a) - lo) * scale);
+        b = b < 0 ? 0 : b > NB - 1 ? NB - 1 : b;
+        cnt[b]++;
+        for (int j = 0; j < 3; j++) {
+          const float q[3] = {f.p[j].x, f.p[j].y, f.p[j].z};
+          for (int k = 0; k < 3; k++) bmn[b][k] = fminf(bmn[b][k], q[k]), bmx[b][k] = fmaxf(bmx[b][k], q[k]);
+        }
+      }
+      double la[NB], ra[NB];
+      int lc[NB], rc[NB];
+      float amn[3] = {INFINITY, INFINITY, INFINITY}, amx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      int c = 0;
+      for (int b = 0; b < NB; b++) {
+        for (int k = 0; k < 3; k++) amn[k] = fminf(amn[k], bmn[b][k]), amx[k] = fmaxf(amx[k], bmx[b][k]);
+        c += cnt[b];
+        lc[b] = c, la[b] = c ? half_area(amn, amx) : 0.0;
+      }
+      for (int k = 0; k < 3; k++) amn[k] = INFINITY, amx[k] = -INFINITY;
+      c = 0;
+      for (int b = NB - 1; b >= 0; b--) {
+        for (int k = 0; k < 3; k++) amn[k] = fminf(amn[k], bmn[b][k]), amx[k] = fmaxf(amx[k], bmx[b][k]);
+        c += cnt[b];
+        rc[b] = c, ra[b] = c ? half_area(amn, amx) : 0.0;
+      }
+      for (int b = 0; b + 1 < NB; b++) {
+        if (!lc[b] || !rc[b + 1]) continue;
+        const double cost = la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+        if (cost < best) best = cost, best_axis = a, best_bin = b;
+      }
+    }
+    if (best_axis >= 0) {
+      const float lo = cmn[best_axis], scale = (float)NB / (cmx[best_axis] - cmn[best_axis]);
+      auto it = std::stable_partition(fp.begin() + first, fp.begin() + first + n, [&](const FacePts &f) {
+        int b = (int)((face_centroid(f, best_axis) - lo) * scale);
+        b = b < 0 ? 0 : b > NB - 1 ? NB - 1 : b;
+        return b <= best_bin;
+      });
+      mid = (int)(it - (fp.begin() + first));
+      if (mid <= 0 || mid >= n) mid = -1;
+    }
+  }
+  if (mid < 0) {
+    int axis = 0;
+    for (int k = 1; k < 3; k++)
+      if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
+    mid = n / 2;
+    std::nth_element(fp.begin() + first, fp.begin() + first + mid, fp.begin() + first + n,
+                     [&](const FacePts &a, const FacePts &b) { return face_centroid(a, axis) < face_centroid(b, axis); });
+  }
+  const int l = build_bin(bn, fp, first, mid, level + 1);
+  const int r = build_bin(bn, fp, first + mid, n - mid, level + 1);
+  bn[me].left = l, bn[me].right = r;
+  return me;
+}
+
+// Bounds of a binary node, padded: no face the binary32 Moller-Trumbore test can accept is ever
+// culled by the (also slack) slab test of the kernel.
+static void padded_node_bounds(const BinNode &b, float mn[3], float mx[3]) {
   float diag = 0.f, mag = 0.f;
   for (int k = 0; k < 3; k++) {
-    diag = fmaxf(diag, mx[k] - mn[k]);
-    mag = fmaxf(mag, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
+    diag = fmaxf(diag, b.mx[k] - b.mn[k]);
+    mag = fmaxf(mag, fmaxf(fabsf(b.mn[k]), fabsf(b.mx[k])));
   }
   const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
-  for (int k = 0; k < 3; k++) mn[k] -= pad, mx[k] += pad;
+  for (int k = 0; k < 3; k++) mn[k] = b.mn[k] - pad, mx[k] = b.mx[k] + pad;
 }
 
-// Median split of [first, first+n) along the longest axis of the centroid bounds; returns the
-// size of the first part.
-static int split_range(std::vector<FacePts> &fp, int first, int n) {
-  float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  auto centroid3 = [](const FacePts &f, float c[3]) {
-    c[0] = f.p[0].x + f.p[1].x + f.p[2].x, c[1] = f.p[0].y + f.p[1].y + f.p[2].y, c[2] = f.p[0].z + f.p[1].z + f.p[2].z;
-  };
-  for (int i = 0; i < n; i++) {
-    float c[3];
-    centroid3(fp[first + i], c);
-    for (int k = 0; k < 3; k++) cmn[k] = fminf(cmn[k], c[k]), cmx[k] = fmaxf(cmx[k], c[k]);
-  }
-  int axis = 0;
-  for (int k = 1; k < 3; k++)
-    if (cmx[k] - cmn[k] > cmx[axis] - cmn[axis]) axis = k;
-  const int mid = n / 2;
-  std::nth_element(fp.begin() + first, fp.begin() + first + mid, fp.begin() + first + n,
-                   [&](const FacePts &a, const FacePts &b) {
-                     float ca[3], cb[3];
-                     centroid3(a, ca), centroid3(b, cb);
-                     return ca[axis] < cb[axis];
-                   });
-  return mid;
-}
-
-// 4-wide search tree over the faces [first, first+n) of a mesh.  Faces are reordered inside
-// the range (each keeps `orig` and `code`).  Which leaf of the reference's tree a face sits in
-// is carried by the face, not by this tree, so the split is free to follow the geometry.
-// Returns the node index; *depth = levels.
-static int build_subtree(std::vector<SubNode4> &sub, std::vector<FacePts> &fp, int first, int n, int *depth) {
-  const int me = (int)sub.size();
-  sub.emplace_back();
-  int parts[4][2];
-  int np = 0;
-  if (n <= 4) {
-    parts[np][0] = first, parts[np][1] = n, np++;
+// One QNode4 from up to four binary nodes: expand the child with the largest surface area until
+// four children (or only leaves) remain; quantise their padded boxes outward onto the node's grid.
+static int collapse4(std::vector<QNode4> &qn, const std::vector<BinNode> &bn, int root, int *depth) {
+  const int me = (int)qn.size();
+  qn.emplace_back();
+  int kids[4], nk = 0;
+  if (bn[root].left < 0) {
+    kids[nk++] = root;
   } else {
-    const int m = split_range(fp, first, n);
-    const int halves[2][2] = {{first, m}, {first + m, n - m}};
-    for (int h = 0; h < 2; h++) {
-      if (halves[h][1] <= 4) {
-        parts[np][0] = halves[h][0], parts[np][1] = halves[h][1], np++;
+    kids[nk++] = bn[root].left, kids[nk++] = bn[root].right;
+    while (nk < 4) {
+      int best = -1;
+      double ba = -1.0;
+      for (int i = 0; i < nk; i++)
+        if (bn[kids[i]].left >= 0) {
+          const double ar = half_area(bn[kids[i]].mn, bn[kids[i]].mx);
+          if (ar > ba) ba = ar, best = i;
+        }
+      if (best < 0) break;
+      const int k = kids[best];
+      kids[best] = bn[k].left;
+      kids[nk++] = bn[k].right;
+    }
+  }
+  float cmn[4][3], cmx[4][3];
+  for (int c = 0; c < nk; c++) padded_node_bounds(bn[kids[c]], cmn[c], cmx[c]);
+  QNode4 nd;
+  memset(&nd, 0, sizeof(nd));
+  for (int a = 0; a < 3; a++) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int c = 0; c < nk; c++) lo = fminf(lo, cmn[c][a]), hi = fmaxf(hi, cmx[c][a]);
+    nd.origin[a] = lo;
+    const double extent = (double)hi - (double)lo;
+    int e = -60;
+    if (extent > 0) e = (int)std::ceil(std::log2(extent / 255.0));
+    e = e < -60 ? -60 : e > 100 ? 100 : e;
+    for (;;) {  // the far corner must land on the grid
+      bool fits = true;
+      for (int c = 0; c < nk; c++)
+        if (std::ceil(std::ldexp((double)cmx[c][a] - (double)lo, -e)) > 255.0) fits = false;
+      if (fits) break;
+      e++;
+    }
+    nd.exp[a] = (int8_t)e;
+    for (int c = 0; c < 4; c++) {
+      if (c < nk) {
+        double ql = std::floor(std::ldexp((double)cmn[c][a] - (double)lo, -e));
+        double qh = std::ceil(std::ldexp((double)cmx[c][a] - (double)lo, -e));
+        ql = ql < 0 ? 0 : ql > 255 ? 255 : ql;
+        qh = qh < 0 ? 0 : qh > 255 ? 255 : qh;
+        nd.qlo[a][c] = (uint8_t)ql, nd.qhi[a][c] = (uint8_t)qh;
       } else {
-        const int q = split_range(fp, halves[h][0], halves[h][1]);
-        parts[np][0] = halves[h][0], parts[np][1] = q, np++;
-        parts[np][0] = halves[h][0] + q, parts[np][1] = halves[h][1] - q, np++;
+        nd.qlo[a][c] = 255, nd.qhi[a][c] = 0;
       }
     }
   }
-  SubNode4 nd;
   int deepest = 0;
   for (int c = 0; c < 4; c++) {
-    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    int child = -1;  // count 0: never visited (empty box)
-    if (c < np) {
-      padded_bounds(fp, parts[c][0], parts[c][1], mn, mx);
-      if (parts[c][1] <= 4) {
-        child = -(parts[c][0] * 8 + parts[c][1]) - 1;
+    int child = -1;  // count 0: never visited
+    if (c < nk) {
+      const BinNode &k = bn[kids[c]];
+      if (k.left < 0) {
+        child = -(k.first * 8 + k.n) - 1;
       } else {
         int d = 0;
-        child = build_subtree(sub, fp, parts[c][0], parts[c][1], &d);
+        child = collapse4(qn, bn, kids[c], &d);
         deepest = std::max(deepest, d);
       }
     }
-    nd.mnx[c] = mn[0], nd.mny[c] = mn[1], nd.mnz[c] = mn[2];
-    nd.mxx[c] = mx[0], nd.mxy[c] = mx[1], nd.mxz[c] = mx[2];
     nd.child[c] = child;
-    nd.pad[c] = 0;
   }
-  sub[me] = nd;
+  qn[me] = nd;
   *depth = deepest + 1;
   return me;
+}
+
+// 4-wide search tree over the faces [first, first+n) of a mesh; faces are reordered inside the
+// range (each keeps `orig` and `code`).  Returns the root's index in `qn`; *depth = levels.
+static int build_subtree(std::vector<QNode4> &qn, std::vector<FacePts> &fp, int first, int n, int *depth) {
+  std::vector<BinNode> bn;
+  bn.reserve((size_t)n);
+  const int root = build_bin(bn, fp, first, n, 0);
+  return collapse4(qn, bn, root, depth);
 }
 
 // bvh.cuh:113-121: bounds; leaf if n <= kMin; else sort by positions_[0].x and
@@ -255,7 +374,7 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
 }
 
 std::string Scene::flatten() {
-  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), subnodes.clear(), faces.clear(),
+  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
   n_pgrams = n_triangles = n_spheres = 0;
@@ -366,10 +485,10 @@ std::string Scene::flatten() {
                            [](const FacePts &a, const FacePts &b) { return a.p[0].x < b.p[0].x; });
         for (int i = 0; i < hb.n; i++) fp[i].orig = i;  // index in the reference's face order
         const int face_base = (int)faces.size();
-        const int sub_base = (int)subnodes.size();
+        const int sub_base = (int)qnodes.size();
         BvhRec br{};
         std::vector<BvhNode> local_nodes;
-        std::vector<SubNode4> local_sub;
+        std::vector<QNode4> local_sub;
         int depth = 0;
         // an empty mesh is a leaf that can never report a hit: it contributes nothing
         int ref_depth = 0;
@@ -377,13 +496,15 @@ std::string Scene::flatten() {
         if (ref_depth > kRefDepthMax) return "mesh tree too deep for the kernel's leaf path codes";
         br.sub_root = hb.n > 0 ? build_subtree(local_sub, fp, 0, hb.n, &depth) + sub_base : -1;
         sub_depth = std::max(sub_depth, depth);
-        if (3 * depth + 1 > kSubStackMax) return "mesh too deep for the kernel's search stack";
+        if (depth > kSubDepthMax) return "mesh too deep for the kernel's search stack";
+        if ((int64_t)face_base + hb.n + 4 >= kMeshMaxFaces || (int64_t)sub_base + (int64_t)local_sub.size() >= kMeshMaxNodes)
+          return "mesh too large for the kernel's 26-bit search-stack entries";
         const int node_base = (int)nodes.size();
         for (BvhNode nd : local_nodes) {  // rebase indices into the scene-wide arrays
           if (nd.right >= 0) nd.left += node_base, nd.right += node_base;
           nodes.push_back(nd);
         }
-        for (SubNode4 nd : local_sub) {
+        for (QNode4 nd : local_sub) {
           for (int c = 0; c < 4; c++) {
             if (nd.child[c] >= 0) {
               nd.child[c] += sub_base;
@@ -392,7 +513,7 @@ std::string Scene::flatten() {
               nd.child[c] = cnt ? -((first + face_base) * 8 + cnt) - 1 : -1;
             }
           }
-          subnodes.push_back(nd);
+          qnodes.push_back(nd);
         }
         if (br.root >= 0) br.root += node_base;
         if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
@@ -408,6 +529,10 @@ std::string Scene::flatten() {
             for (int j = 0; j < 6; j++) face_uv[(size_t)(face_base + fp[i].orig) * 6 + j] = fp[i].uv[j];
         }
         br.mat = hb.mat;
+        br.mag = 0.f;
+        if (!local_nodes.empty())
+          for (int k = 0; k < 3; k++)
+            br.mag = fmaxf(br.mag, fmaxf(fabsf(local_nodes[0].mn[k]), fabsf(local_nodes[0].mx[k])));
         br.has_uv = has_uv ? 1 : 0;
         br.face_base = face_base;
         if (br.root >= 0) {

@@ -83,26 +83,41 @@ struct BvhNode {  // 32 B
   int32_t right;  // negative marks a leaf
 };
 
-// The search structure: one 4-wide tree per mesh over ALL its faces, with conservative
-// (padded) child bounds, stored child-major per plane so one 128-byte fetch (eight 16-byte
-// loads) serves four slab tests.  child[i] >= 0: sub-node index; child[i] < 0: faces, encoded
-// -(first*8 + count) - 1 with count in 1..4; unused slots have an empty box (mn = +inf,
-// mx = -inf) and count 0.
-struct alignas(16) SubNode4 {  // 128 B
-  float mnx[4], mny[4], mnz[4];
-  float mxx[4], mxy[4], mxz[4];
+// The search structure: one 4-wide tree per mesh over ALL its faces (binned-SAH binary tree
+// collapsed to four children per node).  A node is 64 bytes = one 64-byte line per lane and step
+// (measured: a per-lane gather of 64-byte records runs 2.9x the rate of 128-byte ones, see
+// profiles/r02a_gather_microbench.txt): child boxes are 8-bit grid coordinates relative to the
+// node's own corner, grid step 2^exp per axis, rounded OUTWARD from bounds that are themselves
+// padded (scene.hip: padded_bounds), so the decoded box always contains the padded one.
+//   word 0: origin.xyz, exp.xyz (int8) | word 1: qlo x,y,z (one byte per child), qhi x |
+//   word 2: qhi y, qhi z, spare       | word 3: child[4]
+// child[i] >= 0: node index; child[i] < 0: faces, encoded -(first*8 + count) - 1 with count in
+// 1..4; unused slots are -1 (count 0).
+struct alignas(16) QNode4 {  // 64 B
+  float origin[3];
+  int8_t exp[3];
+  int8_t pad0;
+  uint8_t qlo[3][4];
+  uint8_t qhi[3][4];
+  uint32_t pad1[2];
   int32_t child[4];
-  int32_t pad[4];
 };
-constexpr int kSubStackMax = 128;  // most per-lane search stack entries (LDS) a scene may need: 3 * depth + 1 of its
-                                  // deepest search tree (SceneDev::sub_stack; 25 for the 69 k-face mesh, 31 for 1 M faces)
-constexpr int kHitSlots = 8;   // per-lane candidate list: one (code, face, t) entry per leaf holding a hit
-constexpr int kHitWords = 4;   // words per entry: code, face, t (one or two words)
-constexpr int kHitListWords = kHitSlots * kHitWords;  // LDS words per lane next to the search stack
-constexpr int kCoopLanes = 16;   // cooperative finish once at most this many lanes still search (>= 4 lanes each)
-constexpr int kCoopStack = 512;  // per-wave LDS words of the cooperative finish, split evenly between its groups
+constexpr int kSubDepthMax = 100;  // deepest search tree (levels of QNode4) the wave-wide stack can serve
+constexpr int kMeshFaceSlack = 68;  // face-block entries that can wait on the stack while nodes are popped one at a time
+constexpr int kHitSlots = 4;    // per-ray candidate list: one (code, face, t) entry per leaf holding a hit
+constexpr int kHitWords = 3;    // words per entry: code, face, t (binary32: TriangleHit's t, utils.cu:53)
+// Per-wave LDS of the mesh search (render_body, mesh variants): 64 ray records + one two-ended stack.
+// Ray record (words): [0..3] origin, t_to | [4..7] direction, (high word of a binary64 t_to) |
+// [8..11] safe 1/direction, padded far bound | [12..15] hit count, cut, lo_code, claim |
+// [16..27] kHitSlots x (code, face, t).
+constexpr int kMeshRayWords = 16 + kHitSlots * kHitWords;
+constexpr int kMeshStackWords = 512;  // node entries grow up from 0, face-block entries down from the top
+constexpr int kMeshWaveWords = 64 * kMeshRayWords + kMeshStackWords;
+constexpr uint32_t kCodeNone = 0xffffffffu;  // "no cut": no leaf code has bit 0 set (kRefDepthMax = 31)
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
-constexpr int kRefDepthMax = 32;  // decisions below the root that a leaf's path code can hold
+constexpr int kRefDepthMax = 31;  // decisions below the root that a leaf's path code can hold
+constexpr int kMeshMaxFaces = 1 << 23;   // a stack entry is 6 bits of ray + 26 bits of (first face * 8 + count) ...
+constexpr int kMeshMaxNodes = 1 << 26;   // ... or of node index
 
 struct BvhRec {  // one per BVH hitable
   int32_t root;      // reference-tree node index
@@ -110,7 +125,8 @@ struct BvhRec {  // one per BVH hitable
   int32_t has_uv;
   int32_t face_base;  // first face of this mesh: face_uv row = face_base + FaceRec::orig
   int32_t sub_root;   // root of the mesh's 4-wide search tree
-  int32_t pad[3];
+  float mag;          // largest |coordinate| of the mesh's bounds (scales the search's distance slack)
+  int32_t pad[2];
 };
 
 struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the winner only
@@ -139,13 +155,14 @@ struct SceneDev {
   const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
   const BvhRec *bvhs;
   const BvhNode *nodes;
-  const SubNode4 *subnodes;
+  const QNode4 *qnodes;
   const FaceRec *faces;
   const float *face_uv;  // 6 floats per face or nullptr
   const MatRec *mats;
   const TexRec *texs;
   int32_t n_runs, n_mats, n_nodes;
-  int32_t sub_stack;  // per-lane search stack entries this scene needs (0 without meshes)
+  int32_t sub_reserve;  // 3 * (deepest search tree) + 3 + kMeshFaceSlack: stack words the wave-wide search keeps free
+                        // after a wide step (0 without meshes); see mesh_search
   int32_t unsigned_colours;  // 1: no material colour has its sign bit set (not even -0): then every layer
                              // product is +0, positive or NaN and `emitted(0) + product` is the product itself
   CameraDev cam;

@@ -12,7 +12,8 @@ import numpy as np
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG_DIR)  # ray-tracing-cuda_amd/
-LIB_PATH = os.path.join(_ROOT, "lib", "librtmi.so")
+# RTMI_LIB_PATH: diagnostic builds of the same library (tools/mesh_stats.sh); never a different implementation
+LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_ROOT, "lib", "librtmi.so")
 
 TILE = 8
 STATE_WORDS = 6
@@ -78,6 +79,7 @@ SYMBOLS = [
     ("rtmi_rng_get_state", C.c_int, [_frp, C.c_void_p, C.c_int64, _u32p, C.c_void_p]),
     ("rtmi_render", C.c_int, [C.c_void_p, _frp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_last_ray_total", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+    ("rtmi_debug_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_void_p]),
     ("rtmi_untile", C.c_int, [_frp, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_untile_u32", C.c_int, [_frp, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_post_process", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
