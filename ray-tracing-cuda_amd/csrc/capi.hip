@@ -324,7 +324,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;
   if ((rc = upload(s, s->tex_recs, &d.texs))) return rc;
-  d.n_runs = (int)s->runs.size();
+  d.n_runs = (int)s->runs.size() - 4;  // without the padding records
   d.n_mats = (int)s->mat_recs.size();
   d.n_nodes = (int)s->nodes.size();
   d.sub_reserve = s->sub_depth > 0 ? 3 * s->sub_depth + 3 + kMeshFaceSlack : 0;
@@ -476,6 +476,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   }
   const uint32_t variant = pick_variant(s->features);
   int threads = g_threads > 0 ? g_threads : 256;
+  if (threads > 256 && !(variant & F_BVH)) threads = 256;  // only the mesh kernels are built for larger workgroups
   if (g_threads <= 0 && (variant & F_BVH)) {
     // mesh variants keep ~310 B of LDS per lane plus per-workgroup tables: when a deep id stack leaves
     // room for one 256-lane workgroup only, smaller workgroups keep more lanes resident
@@ -553,6 +554,15 @@ int rtmi_debug_counters(const rtmi_scene *sp, unsigned long long out[RTMI_COUNTE
   return RTMI_OK;
 }
 
+#ifdef RTMI_STATS
+// diagnostic builds only (not declared in rtmi.h): per-wave cycle records of the last render
+int rtmi_debug_wave_stats(unsigned long long *out, size_t bytes) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(rtmi::copy_wave_stats(out, bytes));
+  return RTMI_OK;
+}
+#endif
+
 int rtmi_untile(const rtmi_frame *f, const float *d_all_tiles, float *d_image, void *stream) {
   FrameDev d;
   if (!make_frame(f, &d) || !d_all_tiles || !d_image) return fail(RTMI_ERR_INVALID, "bad untile arguments");
@@ -591,8 +601,8 @@ int rtmi_set_schedule(int mode) {
   return RTMI_OK;
 }
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block) {
-  if (blocks_per_cu < 0 || threads_per_block < 0 || (threads_per_block % 64) != 0 || threads_per_block > 256)
-    return fail(RTMI_ERR_INVALID, "threads_per_block must be a multiple of 64, at most 256");
+  if (blocks_per_cu < 0 || threads_per_block < 0 || (threads_per_block % 64) != 0 || threads_per_block > 512)
+    return fail(RTMI_ERR_INVALID, "threads_per_block must be a multiple of 64, at most 512 (256 for scenes without meshes)");
   g_blocks_per_cu = blocks_per_cu;
   g_threads = threads_per_block;
   return RTMI_OK;

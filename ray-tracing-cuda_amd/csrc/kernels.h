@@ -35,6 +35,9 @@ hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);
 hipError_t launch_post(float *d_img, int64_t n, int spp, hipStream_t stream);
+#ifdef RTMI_STATS
+hipError_t copy_wave_stats(unsigned long long *host, size_t bytes);  // diagnostic builds only
+#endif
 // d_bad[4]: see arithmetic_selftest in kernels.hip.
 hipError_t launch_arithmetic_selftest(unsigned long long *d_bad, hipStream_t stream);
 

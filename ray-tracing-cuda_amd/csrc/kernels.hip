@@ -227,8 +227,13 @@ __device__ __forceinline__ f32x16 load_hot_tri(const HotTri *base, int idx) {
 __device__ __forceinline__ f32x8 load_sphere(const SphereRec *base, int idx) {
   return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
 }
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ i32x4 load_run(const Run *base, int idx) {
   return *(const RT_CONSTANT i32x4 *)(uintptr_t)(base + idx);
+}
+__device__ __forceinline__ i32x8 load_bvh_rec(const BvhRec *base, int idx) {
+  return *(const RT_CONSTANT i32x8 *)(uintptr_t)(base + idx);
 }
 
 // bvh.cu:6-30 — "the segment crosses the box surface"; a box that wholly
@@ -256,6 +261,32 @@ __device__ __forceinline__ bool aabb_test(const BvhNode &nd, V3 o, V3 d, T t_to)
     }
   }
   return false;
+}
+
+// The T-independent part of AABB::Hit (bvh.cu:6-30): the smallest plane-crossing time tf that is
+// finite, >= t_from and whose crossing point lies inside the box on the other two axes (+inf if no
+// plane qualifies).  AABB::Hit(box, [t_from, T]) is then exactly `crossing_time <= T`: each plane's
+// own test is `tf <= T` AND these T-independent conditions, and the box test is their OR.
+__device__ __forceinline__ float aabb_crossing_time(const BvhNode &nd, V3 o, V3 d) {
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  float m = INFINITY;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+      const float plane = s == 0 ? nd.mn[i] : nd.mx[i];
+      const float tf = (plane - oo[i]) / dd[i];
+      bool okp = dd[i] != 0.f && fabsf(tf) < INFINITY && T_FROM_F <= tf;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        if (a == i) continue;
+        const float pa = oo[a] + tf * dd[a];
+        okp = okp && nd.mn[a] <= pa && pa <= nd.mx[a];
+      }
+      m = okp ? fminf(m, tf) : m;
+    }
+  }
+  return m;
 }
 
 __device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) {
@@ -353,6 +384,43 @@ __device__ __forceinline__ float ubyte_f32(uint32_t x, int byte) { return (float
 // widened by this fraction of (|o|_inf + largest mesh coordinate) >= |o - p0|_inf on top of it.
 #define MESH_DIST_SLACK 0x1p-16f
 
+// The ray in a node's grid: per axis the time per grid step (idq) and the constants of
+// t_lo = qlo * idq + ka, t_hi = qhi * idq + kb for the child planes qlo - rho and qhi + rho.
+struct NodeFrame {
+  float ka[3], kb[3], idq[3];
+};
+__device__ __forceinline__ void node_frame(uint4 w0, float4 r0, float4 r2, float mag, NodeFrame &f) {
+  const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(r0.x), fabsf(r0.y)), fabsf(r0.z)) + mag);
+  const float oo[3] = {r0.x, r0.y, r0.z}, ii[3] = {r2.x, r2.y, r2.z};
+  const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const int ex = (int)(int8_t)((w0.w >> (8 * a)) & 0xffu);
+    const float oq = ldexpf(oo[a] - org[a], -ex);
+    const float rho = ldexpf(delta, -ex);
+    // finite even for a clamped reciprocal on a coarse grid: |q - oq| >= rho > 0 keeps the product
+    // away from 0 * inf, and med3 keeps it below infinity
+    f.idq[a] = __builtin_amdgcn_fmed3f(ldexpf(ii[a], ex), -1e35f, 1e35f);
+    f.ka[a] = -(oq + rho) * f.idq[a];
+    f.kb[a] = -(oq - rho) * f.idq[a];
+  }
+}
+__device__ __forceinline__ bool child_box_hit(const NodeFrame &f, float qlx, float qly, float qlz, float qhx, float qhy,
+                                              float qhz, float lo0, float hi0) {
+  const float ql[3] = {qlx, qly, qlz}, qh[3] = {qhx, qhy, qhz};
+  float en = -INFINITY, le = INFINITY;
+#pragma unroll
+  for (int a = 0; a < 3; a++) {
+    const float tl = __builtin_fmaf(ql[a], f.idq[a], f.ka[a]);
+    const float th = __builtin_fmaf(qh[a], f.idq[a], f.kb[a]);
+    en = fmaxf(en, fminf(tl, th));
+    le = fminf(le, fmaxf(tl, th));
+  }
+  const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), 1e-5f, en));
+  const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), 1e-5f, le));
+  return lo <= hi;
+}
+
 // Record a face that passed the triangle test with parameter t in its ray's candidate list (`rr` =
 // the ray record).  Same leaf: the smaller t wins, the higher reference index among equal t (what an
 // in-order scan with `t <= t_to` keeps, bvh.cuh:127-134).  A full list keeps the leaves that come
@@ -401,8 +469,10 @@ struct MeshStats {
   // shader cycles (s_memtime) of this wave: [0] sample bookkeeping + camera ray, [1] world list before the mesh,
   // [2] mesh search, [3] replay, [4] shading; of the node steps: [5] pop + node/ray fetch, [6] box tests, [7] pushes;
   // [8] face steps incl. inserts
-  unsigned long long cyc[9];
+  unsigned long long calib;  // two stamps back to back, once per search: what a stamp costs
+  unsigned long long cyc[11];  // [9] search setup before the first step, [10] between steps (loop control)
 };
+__device__ unsigned long long g_wave_stats[16384][16];  // per wave: life, cyc[0..8], wave_queries, node_steps, face_steps
 __device__ __forceinline__ unsigned long long stat_now() {
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t;
@@ -411,8 +481,14 @@ __device__ __forceinline__ unsigned long long stat_now() {
   return t;
 }
 #define RTMI_STAT(x) x
+#if RTMI_STATS >= 2
+#define RTMI_STAT2(x) x  // per-step stamps (a stamp costs several hundred cycles: they distort what they measure)
+#else
+#define RTMI_STAT2(x)
+#endif
 #else
 #define RTMI_STAT(x)
+#define RTMI_STAT2(x)
 #endif
 
 // One search pass for the lanes with `need`: afterwards every such lane's record holds, per
@@ -425,7 +501,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
 #endif
 ) {
   const int lane = (int)(threadIdx.x & 63u);
-  RTMI_STAT(st.searches++; unsigned my_steps = 0;)
+  RTMI_STAT(st.searches++; unsigned my_steps = 0; const unsigned long long tset0 = stat_now();)
   int *stack = wl + 64 * kMeshRayWords;
   const float lo0 = T_FROM_F * 0.999f;
   if (need) {
@@ -448,21 +524,52 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
   int sn = __popcll(nm), sf = 0;
   const int reserve = sc.sub_reserve;
   wave_lds_fence();
+  RTMI_STAT(unsigned long long tprev = stat_now(); st.cyc[9] += tprev - tset0;
+            { const unsigned long long cb = stat_now(); st.calib += cb - tprev; tprev = cb; } (void)tprev;)
   while ((sn | sf) != 0) {
     if (sf >= 64 || sn == 0) {
       // ---------------------------------------------------------------- face step
+      // Few blocks pending (the tail of a search, or a wave with one deep ray among 64): four lanes
+      // per block, one face each -- one memory round trip and one triangle test deep.  Otherwise one
+      // lane per block of up to four faces.
+      const bool wide = sf <= 16;
       const int kf = sf < 64 ? sf : 64;
-      RTMI_STAT(st.face_steps++; st.blocks_popped += kf; my_steps++; const unsigned long long tf0 = stat_now();)
-      const bool mine = lane < kf;
+      RTMI_STAT(st.face_steps++; st.blocks_popped += kf; my_steps++;)
+      RTMI_STAT2(const unsigned long long tf0 = stat_now(); st.cyc[10] += tf0 - tprev;)
+      const int slot = wide ? (lane >> 2) : lane;
+      const bool mine = slot < kf;
       int e = 0;
-      if (mine) e = stack[kMeshStackWords - sf + lane];
+      if (mine) e = stack[kMeshStackWords - sf + slot];
       sf -= kf;
       wave_lds_fence();
       unsigned pend = 0u;  // bit j: face first + j passed the test ...
-      float pt0 = 0.f, pt1 = 0.f, pt2 = 0.f, pt3 = 0.f;  // ... with this t
-      const int owner = (int)((unsigned)e >> 26), fcnt = e & 7, first = (e >> 3) & (kMeshMaxFaces - 1);
+      float pt0 = 0.f, pt1 = 0.f, pt2 = 0.f, pt3 = 0.f;  // ... with this t ...
+      float po0 = 0.f, po1 = 0.f, po2 = 0.f, po3 = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f, pc3 = 0.f;  // ... orig, code
+      const int owner = (int)((unsigned)e >> 26), fcnt = e & 7;
+      int first = (e >> 3) & (kMeshMaxFaces - 1);
       int *rr = wl + owner * kMeshRayWords;
-      if (mine) {
+      if (wide) {
+        const int j = lane & 3;
+        first += j;
+        if (mine && j < fcnt) {
+          const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r1 = *reinterpret_cast<const float4 *>(rr + 4);
+          T t_to;
+          if (DT) {
+            t_to = (T)__hiloint2double(__float_as_int(r1.w), __float_as_int(r0.w));
+          } else {
+            t_to = (T)r0.w;
+          }
+          const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + first);
+          const float4 a = fp4[0], b = fp4[1], c = fp4[2];
+          float t = 0.f, u = 0.f, v = 0.f;
+          bool th = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), mk(r0.x, r0.y, r0.z),
+                                mk(r1.x, r1.y, r1.z), t_to, t, u, v);
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 2
+          th = th && t < -1.f;  // never
+#endif
+          if (th) pend = 1u, pt0 = t, po0 = c.y, pc0 = c.z;
+        }
+      } else if (mine) {
         const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r1 = *reinterpret_cast<const float4 *>(rr + 4);
         T t_to;
         if (DT) {
@@ -489,10 +596,10 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
 #endif
                 if (th) {
                   pend |= 1u << (half * 2 + fi);
-                  if (half * 2 + fi == 0) pt0 = t;
-                  if (half * 2 + fi == 1) pt1 = t;
-                  if (half * 2 + fi == 2) pt2 = t;
-                  if (half * 2 + fi == 3) pt3 = t;
+                  if (half * 2 + fi == 0) pt0 = t, po0 = c.y, pc0 = c.z;
+                  if (half * 2 + fi == 1) pt1 = t, po1 = c.y, pc1 = c.z;
+                  if (half * 2 + fi == 2) pt2 = t, po2 = c.y, pc2 = c.z;
+                  if (half * 2 + fi == 3) pt3 = t, po3 = c.y, pc3 = c.z;
                 }
               }
             }
@@ -508,94 +615,101 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
         if (has && rr[15] == lane) {
           const int j = __builtin_ctz(pend);
           const float t = j == 0 ? pt0 : j == 1 ? pt1 : j == 2 ? pt2 : pt3;
-          const FaceRec *f = sc.faces + (first + j);
-          hit_list_insert(sc, rr, f->code, first + j, f->orig, t);
+          const float fo = j == 0 ? po0 : j == 1 ? po1 : j == 2 ? po2 : po3;
+          const float fc = j == 0 ? pc0 : j == 1 ? pc1 : j == 2 ? pc2 : pc3;
+          hit_list_insert(sc, rr, (uint32_t)__float_as_int(fc), first + j, __float_as_int(fo), t);
           pend &= pend - 1u;
         }
         wave_lds_fence();
       }
-      RTMI_STAT(st.cyc[8] += stat_now() - tf0;)
+      RTMI_STAT2(tprev = stat_now(); st.cyc[8] += tprev - tf0;)
     } else {
       // ---------------------------------------------------------------- node step
+      const bool wide = sn <= 16;  // four lanes per entry, one child box each (see the face step)
       int k = (kMeshStackWords - sn - sf - reserve) / 3;
       k = k < 1 ? 1 : k;
-      k = k > 64 ? 64 : k;
+      k = k > (wide ? 16 : 64) ? (wide ? 16 : 64) : k;
       k = k > sn ? sn : k;
       if (3 * k > kMeshStackWords - sn - sf) {  // cannot happen (see above); never write out of range
         if (lane == 0) atomicAdd(overflow, 1ull);
         break;
       }
-      RTMI_STAT(st.node_steps++; st.nodes_popped += k; my_steps++; const unsigned long long tn0 = stat_now(); unsigned long long tn1 = tn0;)
-      const bool mine = lane < k;
+      RTMI_STAT(st.node_steps++; st.nodes_popped += k; my_steps++;)
+      RTMI_STAT2(const unsigned long long tn0 = stat_now(); unsigned long long tn1 = tn0; st.cyc[10] += tn0 - tprev;)
+      const int slot = wide ? (lane >> 2) : lane;
+      const bool mine = slot < k;
       int e = 0;
-      if (mine) e = stack[sn - 1 - lane];
+      if (mine) e = stack[sn - 1 - slot];
       sn -= k;
       wave_lds_fence();
-      bool h0 = false, h1 = false, h2 = false, h3 = false;
-      int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
       const uint32_t owner_bits = (uint32_t)e & 0xfc000000u;
-      if (mine) {
-        const int owner = (int)((unsigned)e >> 26), idx = e & (kMeshMaxNodes - 1);
-        const uint4 *np = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
-        const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
-        const int *rr = wl + owner * kMeshRayWords;
-        const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r2 = *reinterpret_cast<const float4 *>(rr + 8);
-        const float hi0 = r2.w;
-        RTMI_STAT(tn1 = stat_now();)
-        // the ray in the node's grid: q-coordinate of the origin and time per grid step, per axis
-        const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(r0.x), fabsf(r0.y)), fabsf(r0.z)) + mag);
-        const float oo[3] = {r0.x, r0.y, r0.z}, ii[3] = {r2.x, r2.y, r2.z};
-        const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
-        const uint32_t qlo[3] = {w1.x, w1.y, w1.z}, qhi[3] = {w1.w, w2.x, w2.y};
-        float ka[3], kb[3], idq[3];  // t_lo = qlo * idq + ka, t_hi = qhi * idq + kb
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-          const int ex = (int)(int8_t)((w0.w >> (8 * a)) & 0xffu);
-          const float oq = ldexpf(oo[a] - org[a], -ex);
-          const float rho = ldexpf(delta, -ex);
-          // finite even for a clamped reciprocal on a coarse grid: |q - oq| >= rho > 0 keeps the
-          // product away from 0 * inf, and med3 keeps it below infinity
-          idq[a] = __builtin_amdgcn_fmed3f(ldexpf(ii[a], ex), -1e35f, 1e35f);
-          ka[a] = -(oq + rho) * idq[a];
-          kb[a] = -(oq - rho) * idq[a];
+      const int owner = (int)((unsigned)e >> 26), idx = e & (kMeshMaxNodes - 1);
+      const uint4 *np = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
+      const int *rr = wl + owner * kMeshRayWords;
+      if (wide) {
+        bool hit = false;
+        int child = -1;
+        if (mine) {
+          const int c = lane & 3;
+          const uint4 w0 = np[0], w1 = np[1];
+          const uint2 w2 = *reinterpret_cast<const uint2 *>(np + 2);
+          child = reinterpret_cast<const int *>(np + 3)[c];
+          const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r2 = *reinterpret_cast<const float4 *>(rr + 8);
+          RTMI_STAT2(tn1 = stat_now();)
+          NodeFrame nf;
+          node_frame(w0, r0, r2, mag, nf);
+          const int sh = 8 * c;
+          hit = child != -1 && child_box_hit(nf, (float)((w1.x >> sh) & 0xffu), (float)((w1.y >> sh) & 0xffu),
+                                             (float)((w1.z >> sh) & 0xffu), (float)((w1.w >> sh) & 0xffu),
+                                             (float)((w2.x >> sh) & 0xffu), (float)((w2.y >> sh) & 0xffu), lo0, r2.w);
         }
-        const int cch[4] = {(int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
-        bool hh[4];
+        RTMI_STAT2(const unsigned long long tn2 = stat_now(); st.cyc[5] += tn1 - tn0; st.cyc[6] += tn2 - tn1;)
+        const bool pn = hit && child >= 0, pf = hit && child < 0;
+        const unsigned long long mn_ = __builtin_amdgcn_ballot_w64(pn), mf_ = __builtin_amdgcn_ballot_w64(pf);
+        if (pn) stack[sn + lane_rank(mn_)] = (int)(owner_bits | (uint32_t)child);
+        if (pf) stack[kMeshStackWords - 1 - sf - lane_rank(mf_)] = (int)(owner_bits | (uint32_t)(-(child + 1)));
+        sn += __popcll(mn_);
+        sf += __popcll(mf_);
+        wave_lds_fence();
+        RTMI_STAT2(tprev = stat_now(); st.cyc[7] += tprev - tn2;)
+      } else {
+        bool h0 = false, h1 = false, h2 = false, h3 = false;
+        int c0 = -1, c1 = -1, c2 = -1, c3 = -1;
+        if (mine) {
+          const uint4 w0 = np[0], w1 = np[1], w2 = np[2], w3 = np[3];
+          const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r2 = *reinterpret_cast<const float4 *>(rr + 8);
+          RTMI_STAT2(tn1 = stat_now();)
+          NodeFrame nf;
+          node_frame(w0, r0, r2, mag, nf);
+          const uint32_t qlo[3] = {w1.x, w1.y, w1.z}, qhi[3] = {w1.w, w2.x, w2.y};
+          const int cch[4] = {(int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
+          bool hh[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float en = -INFINITY, le = INFINITY;
-#pragma unroll
-          for (int a = 0; a < 3; a++) {
-            const float tl = __builtin_fmaf(ubyte_f32(qlo[a], c), idq[a], ka[a]);
-            const float th = __builtin_fmaf(ubyte_f32(qhi[a], c), idq[a], kb[a]);
-            en = fmaxf(en, fminf(tl, th));
-            le = fminf(le, fmaxf(tl, th));
-          }
-          const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), 1e-5f, en));
-          const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), 1e-5f, le));
-          hh[c] = cch[c] != -1 && lo <= hi;
+          for (int c = 0; c < 4; c++)
+            hh[c] = cch[c] != -1 && child_box_hit(nf, ubyte_f32(qlo[0], c), ubyte_f32(qlo[1], c), ubyte_f32(qlo[2], c),
+                                                  ubyte_f32(qhi[0], c), ubyte_f32(qhi[1], c), ubyte_f32(qhi[2], c), lo0, r2.w);
+          h0 = hh[0], h1 = hh[1], h2 = hh[2], h3 = hh[3];
+          c0 = cch[0], c1 = cch[1], c2 = cch[2], c3 = cch[3];
         }
-        h0 = hh[0], h1 = hh[1], h2 = hh[2], h3 = hh[3];
-        c0 = cch[0], c1 = cch[1], c2 = cch[2], c3 = cch[3];
-      }
-      RTMI_STAT(const unsigned long long tn2 = stat_now(); st.cyc[5] += tn1 - tn0; st.cyc[6] += tn2 - tn1;)
-      // children that were touched: nodes onto the node end, face blocks onto the face end
+        RTMI_STAT2(const unsigned long long tn2 = stat_now(); st.cyc[5] += tn1 - tn0; st.cyc[6] += tn2 - tn1;)
+        // children that were touched: nodes onto the node end, face blocks onto the face end
 #define RTMI_PUSH_CHILD(H, C)                                                           \
   {                                                                                     \
     const bool pn = (H) && (C) >= 0, pf = (H) && (C) < 0;                               \
-    const unsigned long long mn_ = __ballot(pn), mf_ = __ballot(pf);                    \
+    const unsigned long long mn_ = __builtin_amdgcn_ballot_w64(pn), mf_ = __builtin_amdgcn_ballot_w64(pf); \
     if (pn) stack[sn + lane_rank(mn_)] = (int)(owner_bits | (uint32_t)(C));             \
     if (pf) stack[kMeshStackWords - 1 - sf - lane_rank(mf_)] = (int)(owner_bits | (uint32_t)(-((C) + 1))); \
     sn += __popcll(mn_);                                                                \
     sf += __popcll(mf_);                                                                \
   }
-      RTMI_PUSH_CHILD(h0, c0)
-      RTMI_PUSH_CHILD(h1, c1)
-      RTMI_PUSH_CHILD(h2, c2)
-      RTMI_PUSH_CHILD(h3, c3)
+        RTMI_PUSH_CHILD(h0, c0)
+        RTMI_PUSH_CHILD(h1, c1)
+        RTMI_PUSH_CHILD(h2, c2)
+        RTMI_PUSH_CHILD(h3, c3)
 #undef RTMI_PUSH_CHILD
-      wave_lds_fence();
-      RTMI_STAT(st.cyc[7] += stat_now() - tn2;)
+        wave_lds_fence();
+        RTMI_STAT2(tprev = stat_now(); st.cyc[7] += tprev - tn2;)
+      }
     }
   }
   RTMI_STAT(st.steps_hist[my_steps <= 1 ? 0 : my_steps <= 4 ? 1 : my_steps <= 8 ? 2 : my_steps <= 12 ? 3 : my_steps <= 20 ? 4 : 5]++;)
@@ -772,9 +886,16 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       // replayed leaf.  If more leaves hold hits than the list has slots, the leaves beyond `cut`
       // are left to a further search pass.
       const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
-      int *rr = wl + (int)(threadIdx.x & 63u) * kMeshRayWords;
+      const int lane = (int)(threadIdx.x & 63u);
+      int *rr = wl + lane * kMeshRayWords;
       for (int i = 0; i < run.count; i++) {
-        const BvhRec br = sc.bvhs[run.first + i];
+        BvhRec br;
+        {
+          const i32x8 bw = load_bvh_rec(sc.bvhs, run.first + i);  // wave-uniform: scalar load
+          br.root = bw[0], br.mat = bw[1], br.has_uv = bw[2], br.face_base = bw[3], br.sub_root = bw[4];
+          br.mag = __int_as_float(bw[5]);
+          br.ref_depth = bw[6];
+        }
         T bt_to = t_to;
         bool bhit = false;
         int bface = 0;
@@ -796,11 +917,20 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
 #endif
           );
           RTMI_STAT(const unsigned long long ts1 = stat_now(); st.cyc[2] += ts1 - ts0;)
-          // ---- (2) replay the listed leaves in the reference's visiting order
+          // ---- (2) replay the listed leaves in the reference's visiting order.  The box tests are
+          // spread over the wave: AABB::Hit(box, [t_from, T]) is `crossing time <= T` with a crossing time
+          // that does not depend on T (aabb_crossing_time), so (a) every lane with listed leaves writes one
+          // task per (leaf, level) of their paths into the search's (now empty) stack, (b) all 64 lanes
+          // work the tasks off, whoever's they are, (c) each lane walks its leaves with the running t_to,
+          // looking the crossing times up.  A lane whose leaves do not fit next to the others' waits for
+          // the next round.
+          RTMI_STAT(const unsigned long long tr0 = stat_now(); (void)tr0;)
           uint32_t cut = kCodeNone;
-          if (need) {
-            const int cnt = rr[12];
-            cut = (uint32_t)rr[13];
+          int cnt = 0;
+          if (need) cnt = rr[12], cut = (uint32_t)rr[13];
+          // my leaves in visiting order: slot numbers packed two bits each
+          int ord = 0, nleaf = 0;
+          {
             bool have_last = false;
             uint32_t last = 0u;
             for (int k = 0; k < cnt; k++) {
@@ -814,51 +944,115 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                 }
               }
               if (sel < 0) break;  // the rest was pushed beyond `cut`
-              have_last = true;
-              last = code;
-              const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
-              uint32_t bits = shared ? entered & (0xffffffffu << (32 - shared)) : 0u;
-              int ni = br.root;
-              bool ent = true;
-              for (int lvl = 1;; lvl++) {
-                int left, right;
-                if (ni < lds_nodes) {
-                  left = s_nodes[ni].left, right = s_nodes[ni].right;
-                } else {
-                  left = sc.nodes[ni].left, right = sc.nodes[ni].right;
+              have_last = true, last = code;
+              ord |= sel << (2 * nleaf);
+              nleaf++;
+            }
+          }
+          const int depth_r = br.ref_depth;
+          const int ntask = nleaf * depth_r;
+          // exclusive prefix sum of nleaf (0..4) over the wave, bit plane by bit plane: no LDS round trips
+          const int base = depth_r * (lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 1) != 0)) +
+                                      2 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 2) != 0)) +
+                                      4 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 4) != 0)));
+          int *tasks = wl + 64 * kMeshRayWords;
+          bool todo = ntask > 0;
+          while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+            const int lo = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
+            const bool now = todo && base + ntask - lo <= kMeshStackWords;
+            const int n_now = __builtin_amdgcn_readlane(base + ntask, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo;
+            // (a) tasks: [lane : 6][node : 26], all-ones node = past the leaf
+            if (now) {
+              for (int k = 0; k < nleaf; k++) {
+                const uint32_t code = (uint32_t)rr[16 + ((ord >> (2 * k)) & 3) * kHitWords];
+                int ni = br.root;
+                bool past = false;
+                for (int lvl = 1; lvl <= depth_r; lvl++) {
+                  if (!past) {
+                    int left, right;
+                    if (ni < lds_nodes) {
+                      left = s_nodes[ni].left, right = s_nodes[ni].right;
+                    } else {
+                      left = sc.nodes[ni].left, right = sc.nodes[ni].right;
+                    }
+                    if (right < 0) {
+                      past = true;
+                    } else {
+                      ni = (code & (0x80000000u >> (lvl - 1))) ? right : left;
+                    }
+                  }
+                  tasks[base - lo + k * depth_r + lvl - 1] = (lane << 26) | (past ? (kMeshMaxNodes - 1) : ni);
                 }
-                if (right < 0) break;  // ni is the leaf, and every box on the way was entered
-                const uint32_t bit = 0x80000000u >> (lvl - 1);
-                ni = (code & bit) ? right : left;
-                if (lvl <= shared) {
-                  ent = (bits & bit) != 0u;
-                } else {
+              }
+            }
+            wave_lds_fence();
+            // (b) crossing times, one task per lane and round
+            for (int t0 = 0; t0 < n_now; t0 += 64) {
+              const int t = t0 + lane;
+              if (t < n_now) {
+                const int w = tasks[t];
+                const int ni = w & (kMeshMaxNodes - 1);
+                float m = __int_as_float(0xffffffff);  // marker: past the leaf
+                if (ni != kMeshMaxNodes - 1) {
+                  const int *orr = wl + (int)((unsigned)w >> 26) * kMeshRayWords;
+                  const float4 r0 = *reinterpret_cast<const float4 *>(orr + 0), r1 = *reinterpret_cast<const float4 *>(orr + 4);
                   BvhNode nd;
                   if (ni < lds_nodes) {
                     nd = s_nodes[ni];
                   } else {
                     nd = sc.nodes[ni];
                   }
+                  m = aabb_crossing_time(nd, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+                }
+                tasks[t] = __float_as_int(m);
+              }
+            }
+            wave_lds_fence();
+            // (c) the walk of bvh.cuh:123-158 over my leaves
+            if (now) {
+              for (int k = 0; k < nleaf; k++) {
+                const int sel = (ord >> (2 * k)) & 3;
+                const uint32_t code = (uint32_t)rr[16 + sel * kHitWords];
+                const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
+                uint32_t bits = shared ? entered & (0xffffffffu << (32 - shared)) : 0u;
+                bool ent = true;
+                for (int lvl = 1; lvl <= depth_r; lvl++) {
+                  const int mi = tasks[base - lo + k * depth_r + lvl - 1];
+                  if (mi == (int)0xffffffff) break;  // the node above was the leaf, and every box on the way was entered
+                  const uint32_t bit = 0x80000000u >> (lvl - 1);
+                  if (lvl <= shared) {
+                    ent = (bits & bit) != 0u;
+                  } else {
 #if defined(RTMI_ABLATE) && RTMI_ABLATE == 1
-                  ent = true;
+                    ent = true;
 #else
-                  ent = aabb_test<T>(nd, o, d, bt_to);
+                    ent = (T)__int_as_float(mi) <= bt_to;
 #endif
-                  if (ent) bits |= bit;
+                    if (ent) bits |= bit;
+                  }
+                  if (!ent) break;
                 }
-                if (!ent) break;
-              }
-              have_prev = true;
-              prev_code = code;
-              entered = bits;
-              if (ent) {
-                const T tj = (T)__int_as_float(rr[16 + sel * kHitWords + 2]);
-                if (tj <= bt_to) {
-                  bt_to = tj;
-                  bhit = true;
-                  bface = rr[16 + sel * kHitWords + 1];
+                have_prev = true;
+                prev_code = code;
+                entered = bits;
+                if (ent) {
+                  const T tj = (T)__int_as_float(rr[16 + sel * kHitWords + 2]);
+                  if (tj <= bt_to) {
+                    bt_to = tj;
+                    bhit = true;
+                    bface = rr[16 + sel * kHitWords + 1];
+                  }
                 }
               }
+              todo = false;
+            }
+            wave_lds_fence();
+          }
+          if (nleaf > 0 && depth_r == 0) {  // the root is the only leaf: nothing to test (its box never is)
+            for (int k = 0; k < nleaf; k++) {
+              const int sel = (ord >> (2 * k)) & 3;
+              const T tj = (T)__int_as_float(rr[16 + sel * kHitWords + 2]);
+              if (tj <= bt_to) bt_to = tj, bhit = true, bface = rr[16 + sel * kHitWords + 1];
             }
           }
           need = need && cut != kCodeNone;  // leaves were deferred: search again from `cut` on
@@ -1272,6 +1466,15 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     atomicAdd(&counters[26], life);
     atomicMax(&counters[27], life);
     atomicAdd(&counters[28], 1ull);
+    atomicAdd(&counters[29], st.calib);
+    const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wid < 16384u) {
+      g_wave_stats[wid][0] = life;
+      for (int i = 0; i < 9; i++) g_wave_stats[wid][1 + i] = st.cyc[i];
+      g_wave_stats[wid][10] = wave_queries, g_wave_stats[wid][11] = st.node_steps, g_wave_stats[wid][12] = st.face_steps;
+      g_wave_stats[wid][13] = st.nodes_popped, g_wave_stats[wid][14] = st.insert_rounds;
+      g_wave_stats[wid][15] = (st.cyc[9] << 32) | (st.cyc[10] >> 8);  // setup cycles | loop-control cycles / 256
+    }
   }
 #endif
 }
@@ -1282,15 +1485,18 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 // sit at the 80-VGPR / 6-wave step and are issue-bound (one wave less costs 5 %), so the step is
 // held explicitly instead of being left to the allocator's luck.
 #define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : 6)
+// Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
+// workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
+#define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)
 template <uint32_t F>
-__global__ __launch_bounds__(256, RTMI_MIN_WAVES(F)) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+__global__ __launch_bounds__(RTMI_MAX_THREADS(F), RTMI_MIN_WAVES(F)) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
                                                       uint32_t *__restrict__ states, float *__restrict__ out,
                                                       uint32_t *__restrict__ ray_counts,
                                                       unsigned long long *__restrict__ counters) {
   render_body<F>(sc, fr, lc, states, out, ray_counts, counters);
 }
 template <uint32_t F>
-__global__ __launch_bounds__(256, RTMI_MIN_WAVES(F)) void probe_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
+__global__ __launch_bounds__(RTMI_MAX_THREADS(F), RTMI_MIN_WAVES(F)) void probe_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
                                                      uint32_t *__restrict__ states, float *__restrict__ out,
                                                      uint32_t *__restrict__ ray_counts,
                                                      unsigned long long *__restrict__ counters) {
@@ -1430,6 +1636,11 @@ __global__ __launch_bounds__(256) void arithmetic_selftest(unsigned long long *b
   if (pm1) atomicAdd(&bad[2], pm1);
   if (u01) atomicAdd(&bad[3], u01);
 }
+#ifdef RTMI_STATS
+hipError_t copy_wave_stats(unsigned long long *host, size_t bytes) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_stats), bytes);
+}
+#endif
 hipError_t launch_arithmetic_selftest(unsigned long long *d_bad, hipStream_t stream) {
   hipLaunchKernelGGL(arithmetic_selftest, dim3(4096), dim3(256), 0, stream, d_bad, -1.f, 1.f, 0.f, 1.f);
   return hipGetLastError();
@@ -1479,6 +1690,12 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.tile_order = d_tile_order;
   lc.sparse_items = d_sparse_items;
   lc.sparse_stride = sparse_stride();
+  if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
+    hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
+                                             : reinterpret_cast<const void *>(render_kernel<F>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
   if (probe) {
     hipLaunchKernelGGL(probe_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
                        d_ray_counts, d_counters);
@@ -1494,6 +1711,11 @@ static int occupancy_t(const SceneDev &sc, const FrameDev &fr, int threads) {
   int nb = 0;
   size_t lds = 0;
   (void)make_cfg(F, sc, fr, threads, &lds);
+  if (threads > RTMI_MAX_THREADS(F) || lds > 160 * 1024) return 0;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(render_kernel<F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, render_kernel<F>, threads, lds) != hipSuccess) nb = 0;
   return nb;
 }

@@ -529,6 +529,7 @@ std::string Scene::flatten() {
             for (int j = 0; j < 6; j++) face_uv[(size_t)(face_base + fp[i].orig) * 6 + j] = fp[i].uv[j];
         }
         br.mat = hb.mat;
+        br.ref_depth = ref_depth;
         br.mag = 0.f;
         if (!local_nodes.empty())
           for (int k = 0; k < 3; k++)
@@ -544,6 +545,7 @@ std::string Scene::flatten() {
       }
     }
   }
+  for (int i = 0; i < 4; i++) runs.push_back(Run{-1, 0, 0, 0});  // the kernel fetches runs four at a time
   if (!face_uv.empty()) face_uv.resize(faces.size() * 6, 0.f);
   if (!faces.empty())  // the kernel fetches sub-leaf faces four at a time
     for (int i = 0; i < 4; i++) faces.push_back(FaceRec{});

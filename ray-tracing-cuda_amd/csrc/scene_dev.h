@@ -102,7 +102,7 @@ struct alignas(16) QNode4 {  // 64 B
   uint32_t pad1[2];
   int32_t child[4];
 };
-constexpr int kSubDepthMax = 100;  // deepest search tree (levels of QNode4) the wave-wide stack can serve
+constexpr int kSubDepthMax = 80;   // deepest search tree (levels of QNode4) the wave-wide stack can serve
 constexpr int kMeshFaceSlack = 68;  // face-block entries that can wait on the stack while nodes are popped one at a time
 constexpr int kHitSlots = 4;    // per-ray candidate list: one (code, face, t) entry per leaf holding a hit
 constexpr int kHitWords = 3;    // words per entry: code, face, t (binary32: TriangleHit's t, utils.cu:53)
@@ -126,7 +126,8 @@ struct BvhRec {  // one per BVH hitable
   int32_t face_base;  // first face of this mesh: face_uv row = face_base + FaceRec::orig
   int32_t sub_root;   // root of the mesh's 4-wide search tree
   float mag;          // largest |coordinate| of the mesh's bounds (scales the search's distance slack)
-  int32_t pad[2];
+  int32_t ref_depth;  // decisions on the longest root-to-leaf path of the reference tree (0: the root is a leaf)
+  int32_t pad;
 };
 
 struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the winner only
