@@ -1098,7 +1098,8 @@ struct LaunchCfg {
   int32_t nodes_off;   // byte offset of the staged reference-tree nodes
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
   int32_t mesh_off;    // byte offset of the per-wave mesh-search regions (kMeshWaveWords words each; BVH variants)
-  int32_t pad[2];
+  int32_t exclusive;   // 1: while a wave holds an outlier pixel, its other lanes take no new pixels (they work for it)
+  int32_t pad;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two; kSparseStride unless RTMI_SPARSE_STRIDE overrides it
@@ -1142,7 +1143,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // per-lane pixel state
   int64_t q = 0;
   int pi = 0, pj = 0, k = 0;
-  bool has_px = false, done = false, active = false;
+  bool has_px = false, done = false, active = false, heavy = false;
   V3 color = splat(0.f);
   uint32_t rays = 0;
   unsigned long long ray_total = 0;
@@ -1171,6 +1172,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   for (;;) {
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
     // -------------------------------------------------------- sample / pixel bookkeeping
+    const bool wave_heavy = (F & F_BVH) && lc.exclusive &&
+                            __builtin_amdgcn_ballot_w64(has_px && heavy && (active || k < fr.spp)) != 0ull;
     if (!active && !done) {
       if (has_px && k >= fr.spp) {
         V3 c = color;
@@ -1194,6 +1197,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       }
       while (!has_px && !done) {
         if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (uint32_t)(lc.sparse_stride - 1)) != 0) {
+          if (wave_heavy) break;  // this wave is busy with an outlier pixel: stay a helper
           // the head of the queue holds the outlier tiles: only every sparse_stride-th lane takes
           // pixels there (the others look again next round), so that a wave carries few rays
           // and the mesh search runs in its cooperative mode
@@ -1224,6 +1228,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         rays = 0;
         color = splat(0.f);
         has_px = true;
+        heavy = nq < sparse_limit;
       }
       if (has_px) {
         // ray_tracing.cu:68-74 + camera.cu:57-70
@@ -1690,6 +1695,10 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.tile_order = d_tile_order;
   lc.sparse_items = d_sparse_items;
   lc.sparse_stride = sparse_stride();
+  {
+    const char *e = getenv("RTMI_EXCLUSIVE");  // tuning knob
+    lc.exclusive = e ? atoi(e) : 1;
+  }
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),

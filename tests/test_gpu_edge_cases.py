@@ -141,3 +141,56 @@ def test_colours_with_a_sign_bit_keep_the_emitted_plus_product_addition():
         b.sky()
     rgb, rays = render_both(fill, h=32, w=40, spp=4, depth=12, post=False)
     assert np.signbit(rgb).any() or (rgb < 0).any()
+
+
+def _tiny_sheet():
+    rng = np.random.default_rng(17)
+    n = 24
+    g = (np.arange(n + 1, dtype=np.float64) / n - 0.5) * 0.04
+    X, Z = np.meshgrid(g, g, indexing="ij")
+    Y = 0.002 * np.sin(40.0 * X) * np.cos(55.0 * Z) + rng.uniform(-2e-4, 2e-4, X.shape)
+    P = np.stack([X, Y, Z], axis=-1).astype(np.float32)
+    p00, p10, p01, p11 = P[:-1, :-1], P[1:, :-1], P[:-1, 1:], P[1:, 1:]
+    return np.concatenate([np.stack([p00, p10, p11], axis=2).reshape(-1, 3, 3),
+                           np.stack([p00, p11, p01], axis=2).reshape(-1, 3, 3)], axis=0).astype(np.float32)
+
+
+@pytest.mark.parametrize("dist,mode", [(1e3, "direct"), (1e3, "grazing"), (1e3, "mirror"), (4e3, "mirror"), (2e4, "mirror")])
+def test_tiny_faces_seen_from_far_away(dist, mode):
+    """Faces of size ~1e-3 near the world origin hit by rays that start 1e3..2e4 away: seen directly
+    (as far as the reference's binary32 camera frame can resolve such a view at all), at grazing
+    incidence, and by rays coming back from a distant mirror.  At that range the binary32
+    Moller-Trumbore test (utils.cu:49-85) accepts rays that miss the exact triangle by about
+    4e-7 x distance -- as much as a whole face here -- and the reference, which scans every face of
+    an entered leaf, reports those hits.  The search boxes are widened in proportion to the ray
+    origin's distance (MESH_DIST_SLACK), so the mesh search must still find every face the test
+    accepts: image, ray counts and ray total equal the oracle's."""
+    import torch
+    faces = _tiny_sheet()
+    h, w, spp, depth = 28, 36, 2, 4
+    res = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        b = make(9)
+        grey = b.lambertian(v3(0.8, 0.8, 0.8))
+        if mode == "mirror":
+            # camera just above the sheet looking up at a mirror `dist` away: the rays come back down
+            b.camera_pinhole(v3(0.002, 0.05, 0.001), v3(0.002, 1.0, 0.001), v3(0, 0, 1), float(2.0 * np.arctan(0.012 / dist)), w / h)
+            b.parallelogram([v3(-50, dist, -50), v3(50, dist, -50), v3(-50, dist, 50)], b.metal(v3(0.9, 0.9, 0.9), 0.0))
+        else:
+            elev = 0.02 if mode == "grazing" else 0.6
+            pos = v3(0.3 * dist * 0.01, dist * np.sin(elev), dist * np.cos(elev))
+            b.camera_pinhole(pos, v3(0.0031, 0, 0.0017), v3(0, 1, 0), float(2.0 * np.arctan(0.03 / dist)), w / h)
+        b.bvh(faces, grey, k_min=64)
+        b.sky()
+        res.append(b)
+    o, p = res
+    o_rgb, o_rays, _, o_total = o.render(h, w, spp, depth)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert o_total > h * w * spp * (2.2 if mode == "mirror" else 1.0)  # the sheet is hit at all
+    assert R.total_rays() == o_total
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb)

@@ -164,12 +164,12 @@ def test_many_hit_leaves_along_one_ray(case):
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
-    """Mesh-heavy random worlds rendered five ways -- image order, forced longest-first (probe,
-    outlier spreading, cooperative searches wherever the cost distribution is skewed), as two
-    interleaved shards, and with the cooperative search switched off or limited to the last three
-    lanes -- must give the same image, ray counts and ray total bit for bit.  (The
-    oracle comparison of such worlds is test_random_world_bit_exact; this one is large enough for
-    the scheduler to matter: 192x256 at 64 spp.)"""
+    """Mesh-heavy random worlds rendered six ways -- image order, forced longest-first (probe,
+    outlier pixels spread one per 16 lanes, their waves working for them alone), as two interleaved
+    shards, with the outlier spreading switched off, with one outlier pixel per wave, and without the
+    helper-wave rule -- must give the same image, ray counts and ray total bit for bit.  (The oracle
+    comparison of such worlds is test_random_world_bit_exact; this one is large enough for the
+    scheduler to matter: 192x256 at 64 spp.)"""
     import torch
     from rtmi.scenes import procedural_bunny_mesh
     rng = np.random.default_rng(500 + seed)
@@ -206,13 +206,17 @@ def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
         assert rtmi.lib().rtmi_set_schedule(2) == 0
         forced = run(1)
         sharded = run(2)
-        os.environ["RTMI_COOP_LANES"] = "0"  # tuning knob: every search finished by its own lane
+        os.environ["RTMI_SPARSE_STRIDE"] = "1"  # tuning knob: outlier pixels packed 64 to a wave
         solo = run(1)
-        os.environ["RTMI_COOP_LANES"] = "3"  # ... or only the last three by the wave
+        os.environ["RTMI_SPARSE_STRIDE"] = "64"  # ... or one to a wave
         few = run(1)
+        os.environ.pop("RTMI_SPARSE_STRIDE", None)
+        os.environ["RTMI_EXCLUSIVE"] = "0"  # ... or sharing their wave with ordinary pixels
+        shared = run(1)
     finally:
-        os.environ.pop("RTMI_COOP_LANES", None)
+        os.environ.pop("RTMI_SPARSE_STRIDE", None)
+        os.environ.pop("RTMI_EXCLUSIVE", None)
         rtmi.lib().rtmi_set_schedule(1)
-    for other in (forced, sharded, solo, few):
+    for other in (forced, sharded, solo, few, shared):
         assert np.array_equal(plain[0], other[0]) and np.array_equal(plain[1], other[1]) and plain[2] == other[2]
     assert plain[2] > h * w * spp * 1.2
