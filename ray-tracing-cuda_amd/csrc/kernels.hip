@@ -382,7 +382,9 @@ __device__ __forceinline__ float ubyte_f32(uint32_t x, int byte) { return (float
 // misses the exact triangle by about 4e-7 |o - p0| / sin(smallest angle) (the error of
 // dot(tvec, pvec) / det); the padded, outward-quantised boxes cover a fixed margin, and every box is
 // widened by this fraction of (|o|_inf + largest mesh coordinate) >= |o - p0|_inf on top of it.
+#ifndef MESH_DIST_SLACK  // (a diagnostic build sets it to 0 to show what the far-face tests catch)
 #define MESH_DIST_SLACK 0x1p-16f
+#endif
 
 // The ray in a node's grid: per axis the time per grid step (idq) and the constants of
 // t_lo = qlo * idq + ka, t_hi = qhi * idq + kb for the child planes qlo - rho and qhi + rho.
