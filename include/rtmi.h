@@ -105,6 +105,13 @@ int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int m
  * floats); used when the corners were derived elsewhere (device-side constructors). */
 int rtmi_add_parallelepiped_faces(rtmi_scene *s, const float faces[54], int material);          /* parallelepiped.cu:25-32 */
 int rtmi_add_sky(rtmi_scene *s);                                                                /* sky.cu:16 */
+/* A HitableList appended to the list under construction (HitableList is itself a Hitable,
+ * hitable_list.cuh:8): `l = new HitableList(); l->Append(...); parent->Append(l)`.  The hitables added
+ * between begin and end are its entries; lists nest to any depth.  It counts as one entry of its
+ * parent and holds up to RTMI_MAX_HITABLES entries of its own.  The library inlines it at its position:
+ * the closest hit -- ties included -- is the one the nested call returns (DESIGN.md "List flattening"). */
+int rtmi_list_begin(rtmi_scene *s);
+int rtmi_list_end(rtmi_scene *s);
 /* BVH<Face<HasTexCoord>,AABB>(faces, n, material) (bvh.cuh:170-173).  faces:
  * n*9 floats; uvs: n*6 floats or NULL (Face<false>); material < 0 keeps
  * "material_ptr_ == nullptr" (bvh.cuh:178).  leaf_max is BVHNode::kMin (2048,
@@ -127,8 +134,8 @@ int rtmi_camera_set(rtmi_scene *s, const float frame[21], int is_defocus, double
  * current HIP device.  Synchronous.  Replaces the point in Main where
  * init_world has run and cudaDeviceSynchronize returns (utils.cu:148-152). */
 int rtmi_scene_commit(rtmi_scene *s);
-/* Counts of the flattened scene: {world entries, spheres, parallelograms (incl.
- * box faces), triangles, bvh faces, bvh nodes, materials, textures}. */
+/* Counts of the flattened scene: {entries of the world list (a nested list counts once), spheres,
+ * parallelograms (incl. box faces), triangles, bvh faces, bvh nodes, materials, textures}. */
 int rtmi_scene_stats(const rtmi_scene *s, int64_t out[8]);
 /* Algorithmic bytes one closest-hit query consults; BVH scenes
  * need the measured per-ray node/face visits and report only the fixed part. */

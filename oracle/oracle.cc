@@ -691,6 +691,7 @@ struct Scene {
   std::vector<std::unique_ptr<Texture>> textures;
   std::vector<std::unique_ptr<Material>> materials;
   std::vector<std::unique_ptr<Hitable>> hitables;
+  std::vector<HitableList *> open_lists;  // nested HitableLists under construction (innermost last)
   Counters totals;
 };
 
@@ -760,7 +761,22 @@ int orc_diffuse_light(orc_scene *s, int tex) { return add_mat(s, new DiffuseLigh
 static Material *M(orc_scene *s, int mat) { return mat < 0 ? nullptr : S(s)->materials[mat].get(); }
 static int add_hit(orc_scene *s, Hitable *h) {
   S(s)->hitables.emplace_back(h);
-  return S(s)->world.Append(h) ? 0 : -1;
+  HitableList *into = S(s)->open_lists.empty() ? &S(s)->world : S(s)->open_lists.back();
+  return into->Append(h) ? 0 : -1;
+}
+// A HitableList appended to a HitableList (hitable_list.cuh:8: the list is itself a Hitable): the
+// hitables added between begin and end are its entries, and its Hit() is the nested call of
+// hitable_list.cu:7-25, not an inlined scan.
+int orc_list_begin(orc_scene *s) {
+  HitableList *l = new HitableList();
+  if (add_hit(s, l) != 0) return -1;
+  S(s)->open_lists.push_back(l);
+  return 0;
+}
+int orc_list_end(orc_scene *s) {
+  if (S(s)->open_lists.empty()) return -1;
+  S(s)->open_lists.pop_back();
+  return 0;
 }
 int orc_add_sphere(orc_scene *s, const float c[3], double r, int mat) {
   return add_hit(s, new Sphere(V(c), r, M(s, mat)));

@@ -125,7 +125,7 @@ struct RtTexRec {
 struct RtFlat {
   int n_obj, n_mat, n_tex, error;
 };
-constexpr int kMaxObj = 1024, kMaxMat = 4096, kMaxTex = 4096;
+constexpr int kMaxObj = 16384, kMaxMat = 4096, kMaxTex = 4096;  // records, incl. the entries and brackets of nested lists
 
 __device__ int rt_tex_id(const Texture *t, const Texture **seen, RtTexRec *out, RtFlat *fl) {
   for (int i = 0; i < fl->n_tex; i++)
@@ -195,16 +195,53 @@ __device__ int rt_mat_id(const Material *m, const Material **seen, RtMatRec *out
   return id;
 }
 
+// Record kinds that bracket the entries of a nested HitableList (hitable_list.cuh:8: a list is a
+// Hitable and can be appended to a list); the host replays them as rtmi_list_begin / rtmi_list_end.
+enum : int { RT_LIST_BEGIN = 1001, RT_LIST_END = 1002 };
+constexpr int kMaxListDepth = 16;
+
 __global__ void rt_flatten(const HitableList *world, RtObjRec *objs, RtMatRec *mats, RtTexRec *texs,
                            const Material **mseen, const Texture **tseen, RtFlat *fl) {
   fl->n_obj = fl->n_mat = fl->n_tex = fl->error = 0;
-  const int n = world->list_len();
-  if (n > kMaxObj) {
-    fl->error = 1;
-    return;
-  }
-  for (int i = 0; i < n; i++) {
-    const Hitable *h = world->at(i);
+  // depth-first over the lists with an explicit stack: (list, next entry)
+  const HitableList *lists[kMaxListDepth];
+  int next[kMaxListDepth];
+  int depth = 0;
+  lists[0] = world, next[0] = 0;
+  while (depth >= 0) {
+    const HitableList *cur = lists[depth];
+    if (next[depth] >= cur->list_len()) {
+      if (depth > 0) {
+        if (fl->n_obj >= kMaxObj) {
+          fl->error = 1;
+          return;
+        }
+        RtObjRec e{};
+        e.kind = RT_LIST_END;
+        objs[fl->n_obj++] = e;
+      }
+      depth--;
+      continue;
+    }
+    const int i = next[depth]++;
+    if (fl->n_obj >= kMaxObj) {
+      fl->error = 1;
+      return;
+    }
+    if (cur->at(i)->rt_kind_ == rtapi::H_LIST) {
+      if (depth + 1 >= kMaxListDepth) {
+        fl->error = 5;  // lists nested deeper than this walk's stack
+        return;
+      }
+      RtObjRec b{};
+      b.kind = RT_LIST_BEGIN;
+      objs[fl->n_obj++] = b;
+      depth++;
+      lists[depth] = static_cast<const HitableList *>(cur->at(i));
+      next[depth] = 0;
+      continue;
+    }
+    const Hitable *h = cur->at(i);
     RtObjRec r{};
     r.kind = h->rt_kind_;
     r.material = -1;
@@ -250,7 +287,7 @@ __global__ void rt_flatten(const HitableList *world, RtObjRec *objs, RtMatRec *m
         break;
       }
       default:
-        fl->error = 4;  // a nested HitableList or an unknown hitable
+        fl->error = 4;  // an unknown hitable
         return;
     }
     objs[fl->n_obj++] = r;
@@ -338,6 +375,12 @@ static rtmi_scene *rt_build_scene(const HitableList *d_world, const Camera *d_ca
         break;
       case rtapi::H_SKY:
         RT_ABI(rtmi_add_sky(s));
+        break;
+      case RT_LIST_BEGIN:
+        RT_ABI(rtmi_list_begin(s));
+        break;
+      case RT_LIST_END:
+        RT_ABI(rtmi_list_end(s));
         break;
       case rtapi::H_BVH: {
         const size_t face_bytes = o.has_uv ? sizeof(Face<true>) : sizeof(Face<false>);

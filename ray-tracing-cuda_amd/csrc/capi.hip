@@ -161,9 +161,18 @@ int rtmi_diffuse_light(rtmi_scene *s, int texture) {
   return add_mat(s, MAT_LIGHT, splat(0.f), 0.f, texture);
 }
 
-static int append(rtmi_scene *s, const HostObj &o) {
-  if (S(s)->world.size() >= RTMI_MAX_HITABLES)
+// Every HitableList -- the world and each nested one -- holds at most kMaxHitables entries
+// (hitable_list.cuh:10,20); a nested list counts as ONE entry of its parent.  Nested lists are
+// recorded inlined at their position, which gives the same closest hit (DESIGN.md "List flattening").
+static int count_entry(rtmi_scene *s) {
+  if (S(s)->list_counts.back() >= RTMI_MAX_HITABLES)
     return fail(RTMI_ERR_CAPACITY, "HitableList::kMaxHitables (1024) exceeded");
+  S(s)->list_counts.back()++;
+  return RTMI_OK;
+}
+static int append(rtmi_scene *s, const HostObj &o) {
+  int rc = count_entry(s);
+  if (rc) return rc;
   S(s)->world.push_back(o);
   S(s)->committed = false;
   return RTMI_OK;
@@ -230,6 +239,20 @@ int rtmi_add_parallelepiped_faces(rtmi_scene *s, const float faces[54], int mate
   for (int i = 0; i < 18; i++) o.p[i] = v3(faces + 3 * i);
   return append(s, o);
 }
+int rtmi_list_begin(rtmi_scene *s) {
+  if (!s) return fail(RTMI_ERR_INVALID, "null scene");
+  int rc = count_entry(s);  // the nested list is one entry of the list it is appended to
+  if (rc) return rc;
+  S(s)->list_counts.push_back(0);
+  S(s)->committed = false;
+  return RTMI_OK;
+}
+int rtmi_list_end(rtmi_scene *s) {
+  if (!s) return fail(RTMI_ERR_INVALID, "null scene");
+  if (S(s)->list_counts.size() < 2) return fail(RTMI_ERR_INVALID, "rtmi_list_end without rtmi_list_begin");
+  S(s)->list_counts.pop_back();
+  return RTMI_OK;
+}
 int rtmi_add_sky(rtmi_scene *s) {
   if (!s) return fail(RTMI_ERR_INVALID, "null scene");
   HostObj o{};
@@ -292,6 +315,7 @@ int rtmi_camera_get(const rtmi_scene *s, float out[21]) {
 int rtmi_scene_commit(rtmi_scene *sp) {
   if (!sp) return fail(RTMI_ERR_INVALID, "null scene");
   Scene *s = S(sp);
+  if (s->list_counts.size() != 1) return fail(RTMI_ERR_INVALID, "a nested list is still open (rtmi_list_end missing)");
   if (rtmi_device_count() <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device: librtmi has no CPU fallback");
   free_device(s);
   std::string err = s->flatten();
@@ -355,7 +379,7 @@ int rtmi_scene_stats(const rtmi_scene *sp, int64_t out[8]) {
   tmp.dev_allocs.clear();
   std::string err = tmp.flatten();
   if (!err.empty()) return fail(RTMI_ERR_INVALID, err);
-  out[0] = (int64_t)tmp.world.size();
+  out[0] = (int64_t)tmp.list_counts[0];
   out[1] = (int64_t)tmp.n_spheres;
   out[2] = (int64_t)tmp.n_pgrams;
   out[3] = (int64_t)tmp.n_triangles;

@@ -48,7 +48,8 @@ struct HostBvh {
 struct Scene {
   std::vector<HostTex> texs;
   std::vector<HostMat> mats;
-  std::vector<HostObj> world;  // HitableList order
+  std::vector<HostObj> world;  // HitableList order, nested lists already inlined at their position (scene.hip: flatten)
+  std::vector<int> list_counts{0};  // entries of the world list [0] and of every nested HitableList still open
   std::vector<HostBvh> bvhs;
   CameraDev cam{};
   V3 cam_w{0, 0, 0};

@@ -380,7 +380,7 @@ std::string Scene::flatten() {
   n_pgrams = n_triangles = n_spheres = 0;
   sub_depth = 0;
   if (!has_camera) return "scene has no camera";
-  if (world.size() > 1024) return "world exceeds HitableList::kMaxHitables (1024)";
+  if (list_counts.empty() || list_counts[0] > 1024) return "world exceeds HitableList::kMaxHitables (1024)";
   if (cam.defocus) features |= F_DEFOCUS;
 
   // ---- materials: fold constant textures into the record; image textures by index

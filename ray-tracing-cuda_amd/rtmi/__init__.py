@@ -58,6 +58,8 @@ SYMBOLS = [
     ("rtmi_add_parallelepiped_lengths", C.c_int, [C.c_void_p, _fp, C.c_int, TRANSFORM_FN, C.c_void_p]),
     ("rtmi_add_parallelepiped_faces", C.c_int, [C.c_void_p, _fp, C.c_int]),
     ("rtmi_add_sky", C.c_int, [C.c_void_p]),
+    ("rtmi_list_begin", C.c_int, [C.c_void_p]),
+    ("rtmi_list_end", C.c_int, [C.c_void_p]),
     ("rtmi_add_bvh", C.c_int, [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int]),
     ("rtmi_camera_pinhole", C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double]),
     ("rtmi_camera_defocus", C.c_int, [C.c_void_p, _fp, _fp, _fp, C.c_double, C.c_double, C.c_double, C.c_double]),
@@ -211,6 +213,13 @@ class SceneBuilder:
 
     def sky(self):
         _check(self.L.rtmi_add_sky(self.h), "rtmi_add_sky")
+
+    def list_begin(self):
+        """``l = new HitableList()`` appended to the list under construction; closed by list_end()."""
+        _check(self.L.rtmi_list_begin(self.h), "rtmi_list_begin")
+
+    def list_end(self):
+        _check(self.L.rtmi_list_end(self.h), "rtmi_list_end")
 
     def bvh(self, faces, mat, uvs=None, k_min=2048):
         faces = np.ascontiguousarray(faces, dtype=np.float32).reshape(-1, 9)

@@ -51,6 +51,8 @@ def lib():
         L.orc_add_parallelepiped.argtypes = [C.c_void_p, fp, C.c_int]
         L.orc_add_parallelepiped_lengths.argtypes = [C.c_void_p, fp, C.c_int, _TRANSFORM, C.c_void_p]
         L.orc_add_sky.argtypes = [C.c_void_p]
+        L.orc_list_begin.argtypes = [C.c_void_p]
+        L.orc_list_end.argtypes = [C.c_void_p]
         L.orc_add_bvh.argtypes = [C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int]
         L.orc_camera_pinhole.argtypes = [C.c_void_p, fp, fp, fp, C.c_double, C.c_double]
         L.orc_camera_defocus.argtypes = [C.c_void_p, fp, fp, fp, C.c_double, C.c_double, C.c_double, C.c_double]
@@ -158,6 +160,13 @@ class OracleBuilder:
 
     def sky(self):
         assert self.L.orc_add_sky(self.h) == 0
+
+    def list_begin(self):
+        """A real nested HitableList object (its Hit() is the nested call of hitable_list.cu:7-25)."""
+        assert self.L.orc_list_begin(self.h) == 0
+
+    def list_end(self):
+        assert self.L.orc_list_end(self.h) == 0
 
     def bvh(self, faces, mat, uvs=None, k_min=2048):
         faces = np.ascontiguousarray(faces, dtype=np.float32).reshape(-1, 9)

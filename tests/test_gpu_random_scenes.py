@@ -220,3 +220,64 @@ def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
     for other in (forced, sharded, solo, few, shared):
         assert np.array_equal(plain[0], other[0]) and np.array_equal(plain[1], other[1]) and plain[2] == other[2]
     assert plain[2] > h * w * spp * 1.2
+
+
+def _nested_world(b, rng):
+    """Lists inside lists (hitable_list.cuh:8), with coincident surfaces across nesting levels so that
+    the tie rules of hitable_list.cu:12-20 decide pixels: the nested call accepts its first hit
+    unconditionally and the parent then demands a strictly nearer one."""
+    def col():
+        return v3(*rng.uniform(0.1, 0.9, 3))
+    mats = [b.lambertian(col()), b.lambertian(col()), b.metal(col(), float(rng.uniform(0, 0.4))), b.dielectric(v3(1, 1, 1), 1.5),
+            b.diffuse_light(b.constant_texture(v3(3, 3, 3)))]
+
+    def wall(z, m, dx=0.0):
+        b.parallelogram([v3(-1.5 + dx, -0.2, z), v3(1.5 + dx, -0.2, z), v3(-1.5 + dx, 1.8, z)], mats[m])
+
+    b.sky()
+    b.list_begin()                      # A
+    wall(-2.0, 0)                       #   back wall, material 0 ...
+    b.list_begin()                      #   B inside A
+    wall(-2.0, 1, 0.7)                  #     ... overlapped by a coincident wall of material 1 (a tie, first wins)
+    b.sphere(v3(-0.6, 0.5, -1.0), 0.45, mats[2])
+    b.list_begin()                      #     C inside B
+    b.parallelepiped([v3(0.3, 0.0, -1.4), v3(0.9, 0.0, -1.4), v3(0.3, 0.7, -1.4), v3(0.3, 0.0, -0.8)], mats[3])
+    b.parallelogram([v3(0.3, 0.0, -0.8), v3(0.9, 0.0, -0.8), v3(0.3, 0.7, -0.8)], mats[1])  # coincident with a box face
+    b.list_end()
+    b.list_end()
+    b.triangle([v3(-1.4, 1.2, -1.9), v3(-0.4, 1.2, -1.9), v3(-0.9, 1.9, -1.9)], mats[4])
+    b.list_end()
+    b.list_begin()                      # an empty list, then one holding only the floor
+    b.list_end()
+    b.list_begin()
+    b.sphere(v3(0, -100.2, -1), 100.0, mats[0])
+    b.list_end()
+    wall(-2.0, 2, -0.9)                 # and a coincident wall at world level, after the nested ones
+    for _ in range(int(rng.integers(0, 3))):
+        b.sphere(v3(*rng.uniform(-1, 1, 2), -1.0 + float(rng.uniform(-0.3, 0.3))), float(rng.uniform(0.1, 0.3)), mats[int(rng.integers(0, 4))])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_nested_lists_match_the_nested_oracle(seed):
+    """The library inlines nested HitableLists; the oracle builds them as real nested objects whose
+    Hit() calls recurse (hitable_list.cu:7-25).  Image, ray counts and ray total must agree bit for
+    bit -- including where coincident surfaces of different nesting levels tie."""
+    import torch
+    h, w, spp, depth = 40, 52, 4, 12
+    res = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        rng = np.random.default_rng(900 + seed)
+        b = make(31 + seed)
+        b.camera_pinhole(v3(0, 0.8, 2.2), v3(0, 0.6, -1), v3(0, 1, 0), PI_D / 3, w / h)
+        _nested_world(b, rng)
+        res.append(b)
+    o, p = res
+    o_rgb, o_rays, _, o_total = o.render(h, w, spp, depth)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert R.total_rays() == o_total
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb)

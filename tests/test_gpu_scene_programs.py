@@ -102,3 +102,51 @@ def test_reference_sample_split_mode_single_rank(tmp_path):
     b, log = run_scene("spheres", tmp_path / "b", 40, 48, 3, extra_env={"RT_DIST_MODE": "spp"})
     assert "sample split" in log
     assert np.array_equal(a, b)
+
+
+def test_nested_lists_program(tmp_path):
+    """tests/scenes/nested_lists.cu (a scene program of this repository, same API as the reference's
+    four): HitableLists appended to HitableLists, walked by the flatten kernel and replayed through
+    rtmi_list_begin/end.  The frame equals the same world recorded through the Python binding."""
+    import torch
+    import rtmi
+    from rtmi.scenes import v3, PI_D
+    h, w, spp = 40, 52, 4
+    img, _ = run_scene("nested_lists", tmp_path, h, w, spp)
+    b = rtmi.SceneBuilder(1024)  # Main() seeds with 1024
+    b.camera_pinhole(v3(0, 0.8, 2.2), v3(0, 0.6, -1), v3(0, 1, 0), PI_D / 3, w / h)
+    m0, m1 = b.lambertian(v3(0.2, 0.6, 0.8)), b.lambertian(v3(0.8, 0.3, 0.2))
+    m2, m3 = b.metal(v3(0.7, 0.7, 0.6), 0.25), b.dielectric(v3(1, 1, 1), 1.5)
+    m4 = b.diffuse_light(b.constant_texture(v3(3, 3, 3)))
+
+    def wall(z, m, dx):
+        b.parallelogram([v3(-1.5 + dx, -0.2, z), v3(1.5 + dx, -0.2, z), v3(-1.5 + dx, 1.8, z)], m)
+
+    b.sky()
+    b.list_begin()
+    wall(-2.0, m0, 0.0)
+    b.list_begin()
+    wall(-2.0, m1, np.float32(0.7))
+    b.sphere(v3(-0.6, 0.5, -1.0), 0.45, m2)
+    b.list_begin()
+    b.parallelepiped([v3(0.3, 0.0, -1.4), v3(0.9, 0.0, -1.4), v3(0.3, 0.7, -1.4), v3(0.3, 0.0, -0.8)], m3)
+    b.parallelogram([v3(0.3, 0.0, -0.8), v3(0.9, 0.0, -0.8), v3(0.3, 0.7, -0.8)], m1)
+    b.list_end()
+    b.list_end()
+    b.triangle([v3(-1.4, 1.2, -1.9), v3(-0.4, 1.2, -1.9), v3(-0.9, 1.9, -1.9)], m4)
+    b.list_end()
+    b.list_begin()
+    b.list_end()
+    b.list_begin()
+    b.sphere(v3(0, -100.2, -1), 100.0, m0)
+    b.list_end()
+    wall(-2.0, m2, np.float32(-0.9))
+    assert b.stats()["world"] == 5
+    b.commit()
+    R = rtmi.Renderer(b, h, w, spp, 10).init_rng()
+    R.render()
+    ref, _ = R.untile()
+    torch.cuda.synchronize()
+    ref = ref.cpu().numpy()
+    assert common.rel_l2(img, ref) <= 1e-3
+    assert (img == ref).all(axis=2).mean() > 0.98

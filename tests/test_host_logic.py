@@ -138,6 +138,46 @@ def test_error_behaviour():
     assert "(-4)" in str(e.value)
 
 
+def test_nested_list_bookkeeping():
+    """A HitableList appended to a HitableList (hitable_list.cuh:8): one entry of its parent, up to
+    kMaxHitables entries of its own, any nesting depth; brackets must balance."""
+    L = rtmi.lib()
+    b = rtmi.SceneBuilder(1)
+    white = b.lambertian(v3(1, 1, 1))
+    b.camera_pinhole(v3(0, 0, 1), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+    b.sky()
+    b.list_begin()
+    for _ in range(1024):  # the nested list's own capacity
+        b.sphere(v3(0, 0, 0), 1.0, white)
+    with pytest.raises(rtmi.RtmiError) as e:
+        b.sphere(v3(0, 0, 0), 1.0, white)
+    assert "(-4)" in str(e.value)
+    with pytest.raises(rtmi.RtmiError):
+        b.list_begin()  # a nested list would be entry 1025 of the full list
+    b2 = rtmi.SceneBuilder(1)
+    w2 = b2.lambertian(v3(1, 1, 1))
+    b2.camera_pinhole(v3(0, 0, 1), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+    b2.list_begin()
+    b2.sphere(v3(0, 0, 0), 1.0, w2)
+    b2.list_begin()
+    b2.parallelogram([v3(0, 0, 0), v3(1, 0, 0), v3(0, 1, 0)], w2)
+    b2.parallelepiped([v3(0, 0, 0), v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)], w2)
+    b2.list_end()
+    with pytest.raises(rtmi.RtmiError):
+        b2.commit()  # a list is still open (reported before the missing GPU is)
+    assert b"still open" in L.rtmi_last_error()
+    b2.list_end()
+    with pytest.raises(rtmi.RtmiError):
+        b2.list_end()  # unbalanced
+    b2.sky()
+    st = b2.stats()
+    assert st["world"] == 2 and st["spheres"] == 1 and st["parallelograms"] == 7  # nested entries are inlined
+    for _ in range(1022):
+        b2.sky()
+    with pytest.raises(rtmi.RtmiError):
+        b2.sky()  # the world list itself is full at 1024 entries, the nested list having counted once
+
+
 def test_no_cpu_fallback():
     """Without a GPU every compute entry point must fail loudly, never render on the CPU."""
     L = rtmi.lib()
