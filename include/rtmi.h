@@ -213,13 +213,39 @@ int rtmi_get_workload(int rank, int world_size, int spp);
  *  [3] CudaRandomFloat(0, 1) as fma(x, 2^-32, 2^-33) -- must be 0. */
 int rtmi_selftest_arithmetic(unsigned long long mismatches[4]);
 
-/* Kernel launch configuration knobs (0 = library default). */
+/* Per-call scheduling options of rtmi_render_ex.  The reference fixes its launch shape at compile
+ * time (dim3(8,8) blocks, utils.cu:158); here the shape and the work-queue order are run-time
+ * parameters of ONE call -- no process state is involved.  A zero / negative field keeps the
+ * library default.  None of them changes any pixel's value. */
+typedef struct rtmi_render_opts {
+  int32_t size;              /* sizeof(rtmi_render_opts) of the caller: must match the library's */
+  int32_t schedule;          /* -1 default; 0 = tiles in image order; 1 = longest-first when it can pay (a 2-spp
+                              * probe on scratch RNG states estimates each tile's cost; pixels are indivisible
+                              * serial chains, so starting the expensive ones first shortens the end-of-frame
+                              * tail); 2 = always longest-first */
+  int32_t blocks_per_cu;     /* 0 default (as many workgroups per CU as fit) */
+  int32_t threads_per_block; /* 0 default; a multiple of 64, at most 512 (256 for scenes without meshes) */
+  int32_t sparse_stride;     /* 0 default (16); mesh frames: the outlier tiles at the head of the longest-first
+                              * queue are taken by every sparse_stride-th lane only (power of two, 1..64) */
+  int32_t exclusive;         /* -1 default (1); 1: a wave holding an outlier pixel takes no other new pixels, its
+                              * remaining lanes only help with that pixel's mesh searches; 0: they render too */
+  int32_t outlier_x10;       /* 0 default (20): a tile is an outlier from this many tenths of the mean tile cost */
+  int32_t reserved;
+  void *d_scratch;           /* optional device scratch of the longest-first scheduler, owned by the caller; with it */
+  size_t scratch_bytes;      /* concurrent renders of one scene on several streams share no state.  NULL: the
+                              * scene caches one, which ties renders of that scene to one stream at a time. */
+} rtmi_render_opts;
+/* Bytes of d_scratch the scheduler needs for this frame / shard. */
+size_t rtmi_render_scratch_bytes(const rtmi_frame *f);
+/* rtmi_render with per-call options (opts == NULL: the defaults). */
+int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
+                   float *d_tiles, uint32_t *d_ray_counts, void *stream);
+
+/* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
+ * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
+ * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 environment variables override the built-in defaults of those three
+ * fields and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
-/* Work-queue order of rtmi_render: 0 = tiles in image order; 1 (default) = longest-first when it
- * can pay (a 2-spp probe on scratch RNG states estimates each tile's cost; pixels are indivisible
- * serial chains, so starting the expensive ones first shortens the end-of-frame tail); 2 = always
- * longest-first.  Never changes any pixel's value.  Scheduler scratch is cached in the scene:
- * concurrent rtmi_render calls on ONE scene from several threads are not supported. */
 int rtmi_set_schedule(int mode);
 
 #ifdef __cplusplus

@@ -10,13 +10,18 @@
 // host -> WriteImage("image.jpeg").
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
+
+#include <cctype>
 
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <thread>
 
@@ -415,39 +420,79 @@ static rtmi_scene *rt_build_scene(const HitableList *d_world, const Camera *d_ca
 }
 
 // ---------------------------------------------------------------- RCCL exchange
-// One process per GPU.  rank/world come from the launcher environment (compat/mpi.h); the
-// ncclUniqueId travels through a file named after MASTER_PORT (rank 0 writes, others poll).
+// One process per GPU on ONE node (the reference's mpirun ranks, scenes/spheres.cu:83-98).  rank/world
+// come from the launcher environment (compat/mpi.h).  Rank 0 hands the ncclUniqueId to the others
+// through a small file in RT_RENDEZVOUS_DIR (default /tmp): the file is named after, and carries, a
+// token that is the same for the ranks of one launch and different for any other launch -- RT_RUN_ID
+// or TORCHELASTIC_RUN_ID if set, else the launcher's pid (the ranks' common parent) -- plus
+// MASTER_ADDR:MASTER_PORT.  Rank 0 removes a leftover of that name, creates the file exclusively
+// under a temporary name, writes token + id, and renames it into place; the others accept a file only
+// if its token matches theirs and it is not older than their own start (minus a minute).  A file left behind by a crashed run, or one of a concurrent job,
+// therefore never reaches ncclCommInitRank.
 struct RtComm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1;
 };
 
+struct RtIdFile {
+  char magic[8];
+  char token[120];
+  ncclUniqueId id;
+};
+
+static std::string rt_launch_token() {
+  const char *run = std::getenv("RT_RUN_ID");
+  if (!run) run = std::getenv("TORCHELASTIC_RUN_ID");
+  const char *addr = std::getenv("MASTER_ADDR"), *port = std::getenv("MASTER_PORT");
+  std::string t = run ? std::string("run-") + run : std::string("ppid-") + std::to_string((long)getppid());
+  t += std::string("-") + (addr ? addr : "127.0.0.1") + "-" + (port ? port : "0");
+  for (char &c : t)
+    if (!(std::isalnum((unsigned char)c) || c == '-' || c == '.')) c = '_';
+  if (t.size() > 100) t.resize(100);
+  return t;
+}
+
 static void rt_comm_init(RtComm *c) {
   c->rank = rt_mpi::rank();
   c->world = rt_mpi::size();
   if (c->world <= 1) return;
-  const char *port = std::getenv("MASTER_PORT");
-  std::string path = std::string("/tmp/rtmi_rccl_id_") + (port ? port : "default");
-  ncclUniqueId id;
+  const char *dir = std::getenv("RT_RENDEZVOUS_DIR");
+  const std::string token = rt_launch_token();
+  const std::string path = std::string(dir ? dir : "/tmp") + "/rtmi_rccl_id_" + token;
+  RtIdFile rec;
+  std::memset(&rec, 0, sizeof(rec));
   if (c->rank == 0) {
-    CHECK(ncclGetUniqueId(&id) == ncclSuccess) << "ncclGetUniqueId";
-    std::string tmp = path + ".tmp";
-    std::ofstream(tmp, std::ios::binary).write(reinterpret_cast<const char *>(&id), sizeof(id));
+    CHECK(ncclGetUniqueId(&rec.id) == ncclSuccess) << "ncclGetUniqueId";
+    std::memcpy(rec.magic, "RTMIID1", 8);
+    std::snprintf(rec.token, sizeof(rec.token), "%s", token.c_str());
+    (void)::unlink(path.c_str());  // a leftover of a crashed launch with the same token (pid reuse)
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    (void)::unlink(tmp.c_str());
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+    CHECK(fd >= 0) << "cannot create " << tmp;
+    CHECK(::write(fd, &rec, sizeof(rec)) == (ssize_t)sizeof(rec)) << "short write to " << tmp;
+    (void)::fsync(fd);
+    ::close(fd);
     CHECK(std::rename(tmp.c_str(), path.c_str()) == 0) << "cannot publish " << path;
   } else {
     bool got = false;
-    for (int tries = 0; tries < 600 && !got; tries++) {
+    const time_t not_before = ::time(nullptr) - 60;  // ranks of one launch start within seconds of each other
+    for (int tries = 0; tries < 1200 && !got; tries++) {
+      RtIdFile in;
+      struct stat sb;
       std::ifstream f(path, std::ios::binary);
-      if (f && f.read(reinterpret_cast<char *>(&id), sizeof(id))) got = true;
-      if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+      if (f && ::stat(path.c_str(), &sb) == 0 && sb.st_mtime >= not_before &&
+          f.read(reinterpret_cast<char *>(&in), sizeof(in)) && std::memcmp(in.magic, "RTMIID1", 8) == 0 &&
+          std::strncmp(in.token, token.c_str(), sizeof(in.token)) == 0) {
+        rec = in;
+        got = true;
+      }
+      if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
-    CHECK(got) << "timed out waiting for " << path;
+    CHECK(got) << "timed out waiting for rank 0's " << path;
   }
-  CHECK(ncclCommInitRank(&c->comm, c->world, id, c->rank) == ncclSuccess) << "ncclCommInitRank";
-  if (c->rank == 0) {
-    // every rank holds the id once the communicator exists
-    std::remove(path.c_str());
-  }
+  CHECK(ncclCommInitRank(&c->comm, c->world, rec.id, c->rank) == ncclSuccess) << "ncclCommInitRank";
+  if (c->rank == 0) std::remove(path.c_str());  // every rank holds the id once the communicator exists
 }
 
 // Gather `count` floats from every rank into rank 0's buffer (rank r at offset r*count).

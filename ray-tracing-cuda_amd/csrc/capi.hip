@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -29,8 +30,31 @@ static int hip_fail(hipError_t e, const char *what) {
     if (e__ != hipSuccess) return hip_fail(e__, #expr);  \
   } while (0)
 
-static int g_blocks_per_cu = 0, g_threads = 0;
-static int g_schedule = 1;  // 0: image order, 1: longest-first when it can pay, 2: always longest-first
+// Process-wide DEFAULTS of the scheduling parameters; every rtmi_render call works on its own copy
+// (rtmi_render_ex overrides fields per call).  The RTMI_* environment variables are tuning overrides
+// of the built-in defaults and are read once, when the library is first used.
+static std::mutex g_tune_mu;
+static RenderTuning g_tune;
+static std::once_flag g_tune_once;
+static int env_int(const char *name, int dflt) {
+  const char *e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+static bool valid_stride(int v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; }
+static RenderTuning default_tuning() {
+  std::call_once(g_tune_once, [] {
+    g_tune.schedule = 1;
+    g_tune.blocks_per_cu = 0;
+    g_tune.threads = 0;
+    g_tune.sparse_stride = env_int("RTMI_SPARSE_STRIDE", kSparseStride);
+    if (!valid_stride(g_tune.sparse_stride)) g_tune.sparse_stride = kSparseStride;
+    g_tune.exclusive = env_int("RTMI_EXCLUSIVE", 1) ? 1 : 0;
+    g_tune.outlier_x10 = env_int("RTMI_OUTLIER_X10", 20);
+    if (g_tune.outlier_x10 < 1) g_tune.outlier_x10 = 20;
+  });
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  return g_tune;
+}
 
 static Scene *S(rtmi_scene *s) { return reinterpret_cast<Scene *>(s); }
 static const Scene *S(const rtmi_scene *s) { return reinterpret_cast<const Scene *>(s); }
@@ -476,9 +500,41 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 }
 
 // ------------------------------------------------------------------ render
+static size_t scratch_bytes_of(const FrameDev &d) {
+  const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
+  return n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 64;
+}
+size_t rtmi_render_scratch_bytes(const rtmi_frame *f) {
+  FrameDev d;
+  if (!make_frame(f, &d)) return 0;
+  return scratch_bytes_of(d);
+}
+
 int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float *d_tiles, uint32_t *d_ray_counts,
                 void *stream) {
+  return rtmi_render_ex(sp, f, nullptr, d_states, d_tiles, d_ray_counts, stream);
+}
+
+int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
+                   float *d_tiles, uint32_t *d_ray_counts, void *stream) {
   if (!sp || !d_states || !d_tiles) return fail(RTMI_ERR_INVALID, "null argument");
+  RenderTuning tune = default_tuning();
+  void *user_scratch = nullptr;
+  size_t user_scratch_bytes = 0;
+  if (opts) {
+    if (opts->size != (int32_t)sizeof(rtmi_render_opts)) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.size does not match this library");
+    if (opts->schedule > 2 || opts->blocks_per_cu < 0 || opts->threads_per_block < 0 || (opts->threads_per_block % 64) != 0 ||
+        opts->threads_per_block > 512 || (opts->sparse_stride != 0 && !valid_stride(opts->sparse_stride)) || opts->exclusive > 1 ||
+        opts->outlier_x10 < 0)
+      return fail(RTMI_ERR_INVALID, "rtmi_render_opts field out of range");
+    if (opts->schedule >= 0) tune.schedule = opts->schedule;
+    if (opts->blocks_per_cu > 0) tune.blocks_per_cu = opts->blocks_per_cu;
+    if (opts->threads_per_block > 0) tune.threads = opts->threads_per_block;
+    if (opts->sparse_stride > 0) tune.sparse_stride = opts->sparse_stride;
+    if (opts->exclusive >= 0) tune.exclusive = opts->exclusive;
+    if (opts->outlier_x10 > 0) tune.outlier_x10 = opts->outlier_x10;
+    user_scratch = opts->d_scratch, user_scratch_bytes = opts->scratch_bytes;
+  }
   const Scene *s = S(sp);
   if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
   FrameDev d;
@@ -499,9 +555,9 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     n_cu = it->second;
   }
   const uint32_t variant = pick_variant(s->features);
-  int threads = g_threads > 0 ? g_threads : 256;
+  int threads = tune.threads > 0 ? tune.threads : 256;
   if (threads > 256 && !(variant & F_BVH)) threads = 256;  // only the mesh kernels are built for larger workgroups
-  if (g_threads <= 0 && (variant & F_BVH)) {
+  if (tune.threads <= 0 && (variant & F_BVH)) {
     // mesh variants keep ~310 B of LDS per lane plus per-workgroup tables: when a deep id stack leaves
     // room for one 256-lane workgroup only, smaller workgroups keep more lanes resident
     int best = 0;
@@ -510,7 +566,7 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
       if (lanes > best) best = lanes, threads = t;
     }
   }
-  int per_cu = g_blocks_per_cu > 0 ? g_blocks_per_cu : render_occupancy(variant, s->dev, d, threads);
+  int per_cu = tune.blocks_per_cu > 0 ? tune.blocks_per_cu : render_occupancy(variant, s->dev, d, threads);
   if (per_cu <= 0) per_cu = 1;
   int64_t want = (d.items + threads - 1) / threads;
   int64_t cap = (int64_t)n_cu * per_cu;
@@ -522,17 +578,26 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   const uint32_t *d_order = nullptr, *d_sparse = nullptr;
   const int probe_spp = 2;
   const bool many_tiles = (int64_t)d.local_tiles * 64 > (int64_t)blocks * threads;
-  if (g_schedule == 2 || (g_schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
-    Scene *ms = const_cast<Scene *>(s);  // scheduler scratch is a cache, not scene state
+  if (tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
     const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-    const size_t need = n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 64;
-    if (ms->sched_bytes < need) {
-      if (ms->d_sched) (void)hipFree(ms->d_sched);
-      ms->d_sched = nullptr, ms->sched_bytes = 0;
-      HIP_TRY(hipMalloc(&ms->d_sched, need));
-      ms->sched_bytes = need;
+    const size_t need = scratch_bytes_of(d);
+    void *scratch = user_scratch;
+    if (scratch) {
+      if (user_scratch_bytes < need) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.scratch_bytes < rtmi_render_scratch_bytes(frame)");
+    } else {
+      // no scratch from the caller: the scene keeps one (a cache, not scene state), which ties renders
+      // of this scene to one stream at a time
+      Scene *ms = const_cast<Scene *>(s);
+      std::lock_guard<std::mutex> lk(g_mu);  // (re)allocation only
+      if (ms->sched_bytes < need) {
+        if (ms->d_sched) (void)hipFree(ms->d_sched);
+        ms->d_sched = nullptr, ms->sched_bytes = 0;
+        HIP_TRY(hipMalloc(&ms->d_sched, need));
+        ms->sched_bytes = need;
+      }
+      scratch = ms->d_sched;
     }
-    uint32_t *p_states = reinterpret_cast<uint32_t *>(ms->d_sched);
+    uint32_t *p_states = reinterpret_cast<uint32_t *>(scratch);
     uint32_t *p_rays = p_states + n * RTMI_STATE_WORDS;
     uint32_t *p_cost = p_rays + n;
     uint32_t *p_order = p_cost + nt;
@@ -543,15 +608,15 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
     HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, nullptr, true,
-                          blocks, threads, st));
-    const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / sparse_stride()) / 64 * 64);
-    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, sparse_cap, st));
+                          blocks, threads, tune, st));
+    const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
+    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, sparse_cap, tune.outlier_x10, st));
     d_order = p_order;
     d_sparse = p_max + 1;
   }
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
-                        s->d_counters, d_order, d_sparse, false, blocks, threads, st));
+                        s->d_counters, d_order, d_sparse, false, blocks, threads, tune, st));
   return RTMI_OK;
 }
 
@@ -621,14 +686,18 @@ int rtmi_selftest_arithmetic(unsigned long long *mismatches) {
 }
 int rtmi_set_schedule(int mode) {
   if (mode < 0 || mode > 2) return fail(RTMI_ERR_INVALID, "schedule mode must be 0 (image order), 1 (auto) or 2 (always longest-first)");
-  g_schedule = mode;
+  (void)default_tuning();
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tune.schedule = mode;
   return RTMI_OK;
 }
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block) {
   if (blocks_per_cu < 0 || threads_per_block < 0 || (threads_per_block % 64) != 0 || threads_per_block > 512)
     return fail(RTMI_ERR_INVALID, "threads_per_block must be a multiple of 64, at most 512 (256 for scenes without meshes)");
-  g_blocks_per_cu = blocks_per_cu;
-  g_threads = threads_per_block;
+  (void)default_tuning();
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tune.blocks_per_cu = blocks_per_cu;
+  g_tune.threads = threads_per_block;
   return RTMI_OK;
 }
 

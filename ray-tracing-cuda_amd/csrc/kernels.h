@@ -20,17 +20,26 @@ uint32_t pick_variant(uint32_t features);
 int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads);
 // d_tile_order (nullable): the work queue hands out local tile d_tile_order[k] as its k-th tile.
 // d_sparse_items (nullable; needs d_tile_order): device word, how many leading work items are outlier
-// tiles that mesh kernels spread one pixel per sparse_stride() lanes (launch_tile_order writes it to d_max[1]).
+// tiles that mesh kernels spread one pixel per tune.sparse_stride lanes (launch_tile_order writes it to d_max[1]).
 // probe: launch under the probe_kernel name (the scheduler's cost-estimation pass).
+// Per-call scheduling parameters (capi.hip fills them from rtmi_render_opts over the process defaults).
+struct RenderTuning {
+  int schedule;       // 0 image order, 1 longest-first when it can pay, 2 always longest-first
+  int blocks_per_cu;  // 0: as many as fit
+  int threads;        // 0: chosen per kernel variant
+  int sparse_stride;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two, 1..64)
+  int exclusive;      // 1: a wave holding an outlier pixel takes no other new pixels (its lanes work for it)
+  int outlier_x10;    // a tile is an outlier from this many tenths of the mean tile cost
+};
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, hipStream_t stream);
+                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, const RenderTuning &tune,
+                         hipStream_t stream);
 // Tiles sorted by descending cost (sum of 64 ray counts each); d_cost/d_order hold n_tiles words,
 // d_max two (the largest cost, the sparse item count).
-int sparse_stride();  // kSparseStride, or the RTMI_SPARSE_STRIDE tuning override
-// sparse_cap: work items the grid holds at one pixel per sparse_stride() lanes (a multiple of 64).
+// sparse_cap: work items the grid holds at one pixel per tune.sparse_stride lanes (a multiple of 64).
 hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
-                             uint32_t *d_order, uint32_t sparse_cap, hipStream_t stream);
+                             uint32_t *d_order, uint32_t sparse_cap, int outlier_x10, hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);

@@ -1104,7 +1104,7 @@ struct LaunchCfg {
   int32_t pad;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
-  int32_t sparse_stride;         // power of two; kSparseStride unless RTMI_SPARSE_STRIDE overrides it
+  int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
 };
 
 template <uint32_t F>
@@ -1603,13 +1603,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 }
 
 hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
-                             uint32_t *d_order, uint32_t sparse_cap, hipStream_t stream) {
+                             uint32_t *d_order, uint32_t sparse_cap, int outlier_x10, hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
                      d_max);
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order, d_max + 1,
-                     sparse_cap, (uint32_t)(getenv("RTMI_OUTLIER_X10") ? atoi(getenv("RTMI_OUTLIER_X10")) : 20));
+                     sparse_cap, (uint32_t)outlier_x10);
   return hipGetLastError();
 }
 
@@ -1664,12 +1664,6 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
   return hipGetLastError();
 }
 
-int sparse_stride() {
-  const char *e = getenv("RTMI_SPARSE_STRIDE");  // tuning knob
-  int v = e ? atoi(e) : kSparseStride;
-  return (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : kSparseStride;
-}
-
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
   LaunchCfg lc{};
   lc.tile_order = nullptr;
@@ -1691,16 +1685,13 @@ template <uint32_t F>
 static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                                   uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
                                   const uint32_t *d_sparse_items, bool probe, int blocks, int threads,
-                                  hipStream_t stream) {
+                                  const RenderTuning &tune, hipStream_t stream) {
   size_t lds = 0;
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
   lc.tile_order = d_tile_order;
   lc.sparse_items = d_sparse_items;
-  lc.sparse_stride = sparse_stride();
-  {
-    const char *e = getenv("RTMI_EXCLUSIVE");  // tuning knob
-    lc.exclusive = e ? atoi(e) : 1;
-  }
+  lc.sparse_stride = tune.sparse_stride;
+  lc.exclusive = tune.exclusive;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),
@@ -1759,11 +1750,12 @@ int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, i
 
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, hipStream_t stream) {
+                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, const RenderTuning &tune,
+                         hipStream_t stream) {
 #define X(V) \
   if (variant == (uint32_t)(V)) \
     return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, d_tile_order, d_sparse_items, probe, \
-                                blocks, threads, stream);
+                                blocks, threads, tune, stream);
   RTMI_FOR_EACH_VARIANT(X)
 #undef X
   return hipErrorInvalidValue;

@@ -30,6 +30,19 @@ class Frame(C.Structure):
                 ("post_process", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32)]
 
 
+class RenderOpts(C.Structure):
+    """rtmi_render_opts of include/rtmi.h (per-call scheduling options)."""
+    _fields_ = [("size", C.c_int32), ("schedule", C.c_int32), ("blocks_per_cu", C.c_int32),
+                ("threads_per_block", C.c_int32), ("sparse_stride", C.c_int32), ("exclusive", C.c_int32),
+                ("outlier_x10", C.c_int32), ("reserved", C.c_int32), ("d_scratch", C.c_void_p),
+                ("scratch_bytes", C.c_size_t)]
+
+
+def render_opts(schedule=-1, blocks_per_cu=0, threads_per_block=0, sparse_stride=0, exclusive=-1, outlier_x10=0):
+    return RenderOpts(C.sizeof(RenderOpts), schedule, blocks_per_cu, threads_per_block, sparse_stride, exclusive,
+                      outlier_x10, 0, None, 0)
+
+
 TRANSFORM_FN = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
 
 _lib = None
@@ -80,6 +93,8 @@ SYMBOLS = [
     ("rtmi_rng_set_state", C.c_int, [_frp, C.c_void_p, C.c_int64, _u32p, C.c_void_p]),
     ("rtmi_rng_get_state", C.c_int, [_frp, C.c_void_p, C.c_int64, _u32p, C.c_void_p]),
     ("rtmi_render", C.c_int, [C.c_void_p, _frp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rtmi_render_ex", C.c_int, [C.c_void_p, _frp, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rtmi_render_scratch_bytes", C.c_size_t, [_frp]),
     ("rtmi_last_ray_total", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     ("rtmi_debug_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_void_p]),
     ("rtmi_untile", C.c_int, [_frp, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -303,13 +318,14 @@ class Renderer:
                        "rtmi_rng_set_state")
         return self
 
-    def render(self, count_rays=True):
-        """Enqueue the trace kernel on torch's current stream (asynchronous)."""
+    def render(self, count_rays=True, opts=None):
+        """Enqueue the trace kernel on torch's current stream (asynchronous).  ``opts``: a
+        ``render_opts(...)`` structure with per-call scheduling options (None = the defaults)."""
         with self.torch.cuda.device(self.device):
-            rc = self.L.rtmi_render(self.scene.h, C.byref(self.frame), C.c_void_p(self.states.data_ptr()),
-                                    C.c_void_p(self.tiles.data_ptr()),
-                                    C.c_void_p(self.ray_counts.data_ptr()) if count_rays else None, self._stream())
-        _check(rc, "rtmi_render")
+            rc = self.L.rtmi_render_ex(self.scene.h, C.byref(self.frame), C.byref(opts) if opts is not None else None,
+                                       C.c_void_p(self.states.data_ptr()), C.c_void_p(self.tiles.data_ptr()),
+                                       C.c_void_p(self.ray_counts.data_ptr()) if count_rays else None, self._stream())
+        _check(rc, "rtmi_render_ex")
         return self
 
     def total_rays(self):

@@ -188,35 +188,24 @@ def test_scheduler_paths_agree_on_random_mesh_worlds(seed):
     b.sky()
     b.commit()
 
-    def run(world):
+    def run(world, **opts):
         tiles, counts, total = [], [], 0
+        o = rtmi.render_opts(**opts)
         for r in range(world):
             R = rtmi.Renderer(b, h, w, spp, depth, True, rank=r, world_size=world).init_rng()
-            R.render()
+            R.render(opts=o)
             total += R.total_rays()
             tiles.append(R.tiles), counts.append(R.ray_counts)
         img, cnt = R.untile(torch.cat(tiles, 0).contiguous(), torch.cat(counts, 0).contiguous())
         torch.cuda.synchronize()
         return img.cpu().numpy(), cnt.cpu().numpy(), total
 
-    import os
-    try:
-        assert rtmi.lib().rtmi_set_schedule(0) == 0
-        plain = run(1)
-        assert rtmi.lib().rtmi_set_schedule(2) == 0
-        forced = run(1)
-        sharded = run(2)
-        os.environ["RTMI_SPARSE_STRIDE"] = "1"  # tuning knob: outlier pixels packed 64 to a wave
-        solo = run(1)
-        os.environ["RTMI_SPARSE_STRIDE"] = "64"  # ... or one to a wave
-        few = run(1)
-        os.environ.pop("RTMI_SPARSE_STRIDE", None)
-        os.environ["RTMI_EXCLUSIVE"] = "0"  # ... or sharing their wave with ordinary pixels
-        shared = run(1)
-    finally:
-        os.environ.pop("RTMI_SPARSE_STRIDE", None)
-        os.environ.pop("RTMI_EXCLUSIVE", None)
-        rtmi.lib().rtmi_set_schedule(1)
+    plain = run(1, schedule=0)
+    forced = run(1, schedule=2)
+    sharded = run(2, schedule=2)
+    solo = run(1, schedule=2, sparse_stride=1)    # outlier pixels packed 64 to a wave
+    few = run(1, schedule=2, sparse_stride=64)    # ... or one to a wave
+    shared = run(1, schedule=2, exclusive=0)      # ... or sharing their wave with ordinary pixels
     for other in (forced, sharded, solo, few, shared):
         assert np.array_equal(plain[0], other[0]) and np.array_equal(plain[1], other[1]) and plain[2] == other[2]
     assert plain[2] > h * w * spp * 1.2

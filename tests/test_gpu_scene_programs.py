@@ -150,3 +150,38 @@ def test_nested_lists_program(tmp_path):
     ref = ref.cpu().numpy()
     assert common.rel_l2(img, ref) <= 1e-3
     assert (img == ref).all(axis=2).mean() > 0.98
+
+
+def test_two_ranks_rendezvous_through_the_id_file(tmp_path):
+    """DistributedMain with WORLD_SIZE=2: both ranks must obtain rank 0's ncclUniqueId through the
+    token-named file and enter ncclCommInitRank together, although a stale id file of another launch
+    lies in the rendezvous directory.  On a box with one GPU RCCL then refuses the communicator
+    ("Duplicate GPU detected") -- which both ranks can only report if the hand-shake worked; with two
+    GPUs the job completes and rank 0's frame equals the single-rank frame."""
+    import torch
+    exe = os.path.join(BIN, "spheres")
+    if not os.path.exists(exe):
+        pytest.skip("%s not built" % exe)
+    h, w, spp = 32, 48, 2
+    rdv = tmp_path / "rdv"
+    rdv.mkdir()
+    (rdv / "rtmi_rccl_id_run-other-127.0.0.1-29999").write_bytes(b"RTMIID1\0" + b"x" * 248)  # someone else's
+    procs = []
+    for r in range(2):
+        d = tmp_path / ("r%d" % r)
+        d.mkdir()
+        env = dict(os.environ, RT_HEIGHT=str(h), RT_WIDTH=str(w), RT_SPP=str(spp), RT_DUMP=str(d / "frame.bin"),
+                   RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RT_RUN_ID="pytest-%d" % os.getpid(),
+                   RT_RENDEZVOUS_DIR=str(rdv), NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([exe], cwd=str(d), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=300)[0] for p in procs]
+    if torch.cuda.device_count() >= 2:
+        assert all(p.returncode == 0 for p in procs), logs
+        one, _ = run_scene("spheres", tmp_path, h, w, spp)
+        two = np.fromfile(str(tmp_path / "r0" / "frame.bin"), dtype=np.float32).reshape(h, w, 3)
+        assert np.array_equal(one, two)
+    else:
+        for log in logs:
+            assert "timed out waiting" not in log
+            assert "Duplicate GPU detected" in log, log[-2000:]
+    assert not [f for f in os.listdir(str(rdv)) if "pytest" in f and not f.endswith(".tmp")] or torch.cuda.device_count() < 2

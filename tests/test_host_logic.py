@@ -178,6 +178,28 @@ def test_nested_list_bookkeeping():
         b2.sky()  # the world list itself is full at 1024 entries, the nested list having counted once
 
 
+def test_render_opts_validation():
+    """rtmi_render_ex checks its per-call options before anything else touches them."""
+    import ctypes as C
+    L = rtmi.lib()
+    b = rtmi.SceneBuilder(1)
+    fr = rtmi.make_frame(8, 8, 1)
+    dummy = C.c_void_p(16)  # never dereferenced: argument checks come first
+    bad_size = rtmi.render_opts()
+    bad_size.size = 12
+    assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(bad_size), dummy, dummy, None, None) == -1
+    assert b"size" in L.rtmi_last_error()
+    for kw in (dict(schedule=3), dict(threads_per_block=100), dict(threads_per_block=1024), dict(sparse_stride=12),
+               dict(exclusive=2), dict(blocks_per_cu=-1)):
+        o = rtmi.render_opts(**kw)
+        assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1, kw
+        assert b"out of range" in L.rtmi_last_error()
+    ok = rtmi.render_opts(schedule=2, sparse_stride=8, exclusive=0)
+    assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(ok), dummy, dummy, None, None) == -1
+    assert b"not committed" in L.rtmi_last_error()  # the options passed; the scene is what is missing
+    assert L.rtmi_render_scratch_bytes(C.byref(fr)) == 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 64
+
+
 def test_no_cpu_fallback():
     """Without a GPU every compute entry point must fail loudly, never render on the CPU."""
     L = rtmi.lib()
