@@ -365,6 +365,8 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->runs, &d.runs))) return rc;
   if ((rc = upload(s, s->spheres, &d.spheres))) return rc;
   if ((rc = upload(s, s->tris, &d.tris))) return rc;
+  if ((rc = upload(s, s->pair_boxes, &d.pair_boxes))) return rc;
+  if ((rc = upload(s, s->pair_pts, &d.pair_pts))) return rc;
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
   if ((rc = upload(s, s->qnodes, &d.qnodes))) return rc;
@@ -373,6 +375,8 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;
   if ((rc = upload(s, s->tex_recs, &d.texs))) return rc;
   d.n_runs = (int)s->runs.size() - 4;  // without the padding records
+  d.n_pairs = (int)s->pair_pts.size();
+  d.list_mag = s->list_mag;
   d.n_mats = (int)s->mat_recs.size();
   d.n_nodes = (int)s->nodes.size();
   d.sub_reserve = s->sub_depth > 0 ? 3 * s->sub_depth + 3 + kMeshFaceSlack : 0;

@@ -224,6 +224,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x16 load_hot_tri(const HotTri *base, int idx) {
   return *(const RT_CONSTANT f32x16 *)(uintptr_t)(base + idx);
 }
+__device__ __forceinline__ f32x8 load_pair_box(const PairBox *base, int idx) {
+  return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
+}
 __device__ __forceinline__ f32x8 load_sphere(const SphereRec *base, int idx) {
   return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
 }
@@ -471,6 +474,7 @@ struct MeshStats {
   // shader cycles (s_memtime) of this wave: [0] sample bookkeeping + camera ray, [1] world list before the mesh,
   // [2] mesh search, [3] replay, [4] shading; of the node steps: [5] pop + node/ray fetch, [6] box tests, [7] pushes;
   // [8] face steps incl. inserts
+  unsigned long long cull_bits, cull_rays, cull_iters;  // culled list scan: candidate pairs, rays, wave iterations
   unsigned long long calib;  // two stamps back to back, once per search: what a stamp costs
   unsigned long long cyc[11];  // [9] search setup before the first step, [10] between steps (loop control)
 };
@@ -733,8 +737,9 @@ struct Hit {
 // lanes); a lane that is not tracing passes live = false and gets an unused result.  The other
 // variants are only entered by tracing lanes and pass true.
 template <uint32_t F>
-__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, int *wl,
-                                           unsigned long long *overflow, V3 o, V3 d, bool live
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes,
+                                           const float4 *s_pairs, int *wl, unsigned long long *overflow, V3 o, V3 d,
+                                           bool live
 #ifdef RTMI_STATS
                                            , MeshStats &st
 #endif
@@ -756,6 +761,15 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
     sa2 = 2 * sa;
   }
 
+  // the ray as the culled list scan wants it: clamped reciprocal, origin shifted by the distance slack
+  V3 cull_inv = splat(0.f), cull_olo = splat(0.f), cull_ohi = splat(0.f);
+  if ((F & F_TRIS) && s_pairs != nullptr) {
+    cull_inv = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
+    const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.list_mag);
+    cull_olo = mk(o.x + delta, o.y + delta, o.z + delta);  // against a box's lower planes, moved out by delta ...
+    cull_ohi = mk(o.x - delta, o.y - delta, o.z - delta);  // ... and its upper planes
+  }
+
   for (int ri = 0; ri < sc.n_runs; ri++) {
     const i32x4 rv = load_run(sc.runs, ri);
     Run run;
@@ -769,7 +783,82 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       t_to = acc ? ts : t_to;
       win = acc ? make_id(RUN_SKY, 0) : win;
     }
-    if ((F & F_TRIS) && live && run.kind == RUN_TRIS) {
+    if ((F & F_TRIS) && live && run.kind == RUN_TRIS && s_pairs != nullptr) {
+      // Culled scan (DESIGN.md "World-list scan").  The reference tests every entry of the list against
+      // every ray (hitable_list.cu:11-22); what it RETURNS only depends on the entries whose test can
+      // succeed, visited in list order.  Lanes of a wave carry unrelated rays, so no entry can be
+      // skipped for the whole wave -- but each lane can skip its own: (1) every pair's padded bounds
+      // (one s_load_dwordx8, wave-uniform) against the lane's ray: a slab test, 27 instructions
+      // instead of the 140 of two triangle tests, builds a bit mask of the pairs this ray comes near;
+      // (2) while any lane has bits left, each lane takes ITS next pair -- a different one per lane,
+      // corners gathered from LDS -- and runs the reference's two triangle tests on it.  A lane visits
+      // its pairs in list order with its own running t_to, so acceptance and ties are as in the full
+      // scan; a pair outside the mask cannot pass the triangle test (the bounds carry the same padding
+      // and distance slack as the mesh search boxes).
+      const int pair0 = run.first >> 1;
+      const float lo0 = T_FROM_F * 0.999f;
+      for (int c0 = 0; c0 < run.count; c0 += 32) {
+        const int nc = run.count - c0 < 32 ? run.count - c0 : 32;
+        const float hi0 = (float)t_to * 1.0001f + 1e-6f;
+        uint32_t mask = 0u;
+        f32x8 nxt = load_pair_box(sc.pair_boxes, pair0 + c0);
+        for (int i = 0; i < nc; i++) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the plain scan below
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x8 bx = nxt;
+          nxt = load_pair_box(sc.pair_boxes, pair0 + c0 + i + 1);  // (one inert record of padding at the end)
+          __builtin_amdgcn_sched_barrier(0);
+          const float t0x = (bx[0] - cull_olo.x) * cull_inv.x, t1x = (bx[3] - cull_ohi.x) * cull_inv.x;
+          const float t0y = (bx[1] - cull_olo.y) * cull_inv.y, t1y = (bx[4] - cull_ohi.y) * cull_inv.y;
+          const float t0z = (bx[2] - cull_olo.z) * cull_inv.z, t1z = (bx[5] - cull_ohi.z) * cull_inv.z;
+          const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+          const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+          const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), 1e-5f, en));
+          const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), 1e-5f, le));
+          mask |= lo <= hi ? 1u << i : 0u;
+        }
+        RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
+        while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+          RTMI_STAT(st.cull_iters++;)
+          if (mask != 0u) {
+            const int j = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            const float4 *pp = s_pairs + (size_t)(pair0 + c0 + j) * 4;
+            const float4 qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+            const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
+            const int flags = __float_as_int(qd.x);
+            const int tri = run.first + 2 * (c0 + j);
+            float t = 0.f, u = 0.f, v = 0.f;
+            const V3 e1 = p1 - p0, e2 = p2 - p0;  // utils.cu:54-55, the subtractions scene.hip: make_tri does
+            const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(d, e2), o, d, t_to, t, u, v);
+            {
+              bool acc = hit_a && (!ok || (T)t < t_to);
+              ok = ok || acc;
+              t_to = acc ? (T)t : t_to;
+              win = acc ? make_id(RUN_TRIS, tri) : win;
+              if (F & F_TEX) {
+                bu = acc ? u : bu;
+                bv = acc ? v : bv;
+              }
+            }
+            if (flags & PAIR_SECOND) {  // parallelogram.cu:33: the second triangle is tried only when the first missed
+              const V3 e1b = p2 - p1, e2b = p3 - p1;
+              bool hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(d, e2b), o, d, t_to, t, u, v);
+              hit_b = hit_b && !hit_a;
+              bool acc = hit_b && (!ok || (T)t < t_to);
+              ok = ok || acc;
+              t_to = acc ? (T)t : t_to;
+              win = acc ? make_id(RUN_TRIS, tri + 1) : win;
+              if (F & F_TEX) {
+                bu = acc ? u : bu;
+                bv = acc ? v : bv;
+              }
+            }
+          }
+        }
+      }
+    } else if ((F & F_TRIS) && live && run.kind == RUN_TRIS) {
+      // Plain scan (lists too long for the LDS staging of the culled one).
       // Records come in (first, second) pairs: a Parallelogram's two triangles, or a lone
       // Triangle followed by an inert record.  Two SGPR buffers ping-pong: while record A
       // is tested the fetch of B is in flight, and vice versa.  Scalar-memory waits are
@@ -1101,7 +1190,7 @@ struct LaunchCfg {
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
   int32_t mesh_off;    // byte offset of the per-wave mesh-search regions (kMeshWaveWords words each; BVH variants)
   int32_t exclusive;   // 1: while a wave holds an outlier pixel, its other lanes take no new pixels (they work for it)
-  int32_t pad;
+  int32_t pairs_off;   // byte offset of the staged PairPts records, -1: not staged (plain list scan)
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
@@ -1125,6 +1214,13 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   if (F & F_BVH)
     wl = reinterpret_cast<int *>(smem + lc.mesh_off) +
          __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kMeshWaveWords;
+  const float4 *s_pairs = nullptr;  // corners of the world-list pairs (culled scan) or nullptr (plain scan)
+  if ((F & F_TRIS) && lc.pairs_off >= 0) {
+    s_pairs = reinterpret_cast<const float4 *>(smem + lc.pairs_off);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.pair_pts);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.pairs_off);
+    for (int w = threadIdx.x; w < sc.n_pairs * 16; w += blockDim.x) dst[w] = src[w];
+  }
   const bool mats_in_lds = lc.lds_mats > 0;
   const bool fast_fold = mats_in_lds && !lc.wide_ids && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
@@ -1270,7 +1366,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
     Hit h = {};
     if (F & F_BVH)  // every lane goes in: see closest_hit
-      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, wl, counters + 2, o, d, active
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_pairs, wl, counters + 2, o, d, active
 #ifdef RTMI_STATS
                          , st
 #endif
@@ -1278,7 +1374,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
     if (active) {
       if (!(F & F_BVH))
-        h = closest_hit<F>(sc, s_nodes, 0, nullptr, nullptr, o, d, true
+        h = closest_hit<F>(sc, s_nodes, 0, s_pairs, nullptr, nullptr, o, d, true
 #ifdef RTMI_STATS
                            , st
 #endif
@@ -1474,6 +1570,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     atomicMax(&counters[27], life);
     atomicAdd(&counters[28], 1ull);
     atomicAdd(&counters[29], st.calib);
+    atomicAdd(&counters[30], st.cull_bits);
+    atomicAdd(&counters[31], st.cull_iters);
+    atomicAdd(&counters[3], st.cull_rays);
     const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (wid < 16384u) {
       g_wave_stats[wid][0] = life;
@@ -1491,7 +1590,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 // Second launch bound = waves per SIMD the register allocation must allow: the list-only variants
 // sit at the 80-VGPR / 6-wave step and are issue-bound (one wave less costs 5 %), so the step is
 // held explicitly instead of being left to the allocator's luck.
-#define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : 6)
+#define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : ((F) & F_TRIS) ? 5 : 6)
 // Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
 // workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
 #define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)
@@ -1664,6 +1763,15 @@ hipError_t launch_rng_init(uint64_t seed, const FrameDev &fr, const uint32_t *d_
   return hipGetLastError();
 }
 
+// RTMI_PLAIN_LIST=1 (read once): keep the uncultured list scan, for A/B measurements
+static bool plain_list_scan() {
+  static const bool v = [] {
+    const char *e = getenv("RTMI_PLAIN_LIST");
+    return e && atoi(e) != 0;
+  }();
+  return v;
+}
+
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes) {
   LaunchCfg lc{};
   lc.tile_order = nullptr;
@@ -1677,7 +1785,10 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
   size_t soff = (noff + (size_t)lc.lds_nodes * sizeof(BvhNode) + 15) & ~(size_t)15;
   lc.mesh_off = (int32_t)soff;
-  *lds_bytes = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
+  size_t poff = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
+  const bool cull = (variant & F_TRIS) && sc.n_pairs > 0 && sc.n_pairs <= kLdsPairs && !plain_list_scan();
+  lc.pairs_off = cull ? (int32_t)poff : -1;
+  *lds_bytes = poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0);
   return lc;
 }
 

@@ -61,6 +61,9 @@ struct Scene {
   std::vector<Run> runs;
   std::vector<SphereRec> spheres;
   std::vector<HotTri> tris;
+  std::vector<PairBox> pair_boxes;
+  std::vector<PairPts> pair_pts;
+  float list_mag = 0.f;
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;
   std::vector<BvhNode> nodes;

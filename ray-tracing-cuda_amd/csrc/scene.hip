@@ -31,14 +31,45 @@ static HotTri hot_tri(V3 p0, V3 p1, V3 p2, int mat, int flags) {
   return h;
 }
 
+// The per-pair records of the culled list scan: corners and padded bounds (n = 3 or 4 points).
+static void push_pair(Scene &s, const V3 *p, int n, int flags) {
+  PairPts pp{};
+  const V3 q[4] = {p[0], p[1], p[2], n == 4 ? p[3] : p[2]};
+  for (int c = 0; c < 3; c++) {
+    const float x[4] = {c == 0 ? q[0].x : c == 1 ? q[0].y : q[0].z, c == 0 ? q[1].x : c == 1 ? q[1].y : q[1].z,
+                        c == 0 ? q[2].x : c == 1 ? q[2].y : q[2].z, c == 0 ? q[3].x : c == 1 ? q[3].y : q[3].z};
+    pp.p0[c] = x[0], pp.p1[c] = x[1], pp.p2[c] = x[2], pp.p3[c] = x[3];
+  }
+  pp.flags = flags;
+  PairBox bx{};
+  float diag = 0.f, mag = 0.f;
+  for (int c = 0; c < 3; c++) {
+    const float x[4] = {pp.p0[c], pp.p1[c], pp.p2[c], pp.p3[c]};
+    bx.mn[c] = fminf(fminf(x[0], x[1]), fminf(x[2], x[3]));
+    bx.mx[c] = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
+    diag = fmaxf(diag, bx.mx[c] - bx.mn[c]);
+    mag = fmaxf(mag, fmaxf(fabsf(bx.mn[c]), fabsf(bx.mx[c])));
+  }
+  // the padding of the mesh search boxes (padded_node_bounds): what the binary32 triangle test can accept
+  // beyond the exact triangle at short range; the distance-proportional part is added at query time
+  const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
+  for (int c = 0; c < 3; c++) bx.mn[c] -= pad, bx.mx[c] += pad;
+  s.list_mag = fmaxf(s.list_mag, mag);
+  s.pair_pts.push_back(pp);
+  s.pair_boxes.push_back(bx);
+}
+
 // parallelogram.cu:10-15 + the two triangles of parallelogram.cu:25,33
-static void push_pgram(std::vector<HotTri> &out, V3 p0, V3 p1, V3 p2, int mat) {
+static void push_pgram(Scene &s, V3 p0, V3 p1, V3 p2, int mat) {
+  std::vector<HotTri> &out = s.tris;
   V3 p3 = p1 + p2 - p0;
   const HotTri first = hot_tri(p0, p1, p2, mat, TRI_PGRAM);
   HotTri second = hot_tri(p1, p2, p3, mat, TRI_PGRAM | TRI_SECOND);
   if (memcmp(first.e2, second.e2, sizeof(first.e2)) == 0) second.flags |= TRI_SAME_E2;  // p3 - p1 == p2 - p0 exactly
   out.push_back(first);
   out.push_back(second);
+  const V3 q[4] = {p0, p1, p2, p3};
+  push_pair(s, q, 4, PAIR_SECOND | ((second.flags & TRI_SAME_E2) ? PAIR_SAME_E2 : 0));
 }
 
 // parallelepiped.cu:8-18: derive the four opposite corners.
@@ -374,6 +405,7 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
 }
 
 std::string Scene::flatten() {
+  pair_boxes.clear(), pair_pts.clear(), list_mag = 0.f;
   runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
@@ -441,6 +473,7 @@ std::string Scene::flatten() {
         if (!check_mat(ob.mat)) return "triangle without a valid material";
         tris.push_back(hot_tri(ob.p[0], ob.p[1], ob.p[2], ob.mat, 0));
         tris.push_back(HotTri{});  // inert second record: the world-list loop walks pairs
+        push_pair(*this, ob.p, 3, 0);
         push_run(RUN_TRIS, (int)tris.size() - 2);
         features |= F_TRIS;
         n_triangles++;
@@ -449,7 +482,7 @@ std::string Scene::flatten() {
       }
       case OBJ_PGRAM: {
         if (!check_mat(ob.mat)) return "parallelogram without a valid material";
-        push_pgram(tris, ob.p[0], ob.p[1], ob.p[2], ob.mat);
+        push_pgram(*this, ob.p[0], ob.p[1], ob.p[2], ob.mat);
         push_run(RUN_TRIS, (int)tris.size() - 2);
         features |= F_TRIS;
         n_pgrams++;
@@ -459,7 +492,7 @@ std::string Scene::flatten() {
       case OBJ_BOX: {
         if (!check_mat(ob.mat)) return "parallelepiped without a valid material";
         for (int fidx = 0; fidx < 6; fidx++) {  // the six faces in AddCorner order
-          push_pgram(tris, ob.p[fidx * 3], ob.p[fidx * 3 + 1], ob.p[fidx * 3 + 2], ob.mat);
+          push_pgram(*this, ob.p[fidx * 3], ob.p[fidx * 3 + 1], ob.p[fidx * 3 + 2], ob.mat);
           push_run(RUN_TRIS, (int)tris.size() - 2);
           n_pgrams++;
           bytes_per_ray += 40;
@@ -552,6 +585,7 @@ std::string Scene::flatten() {
   if (!tris.empty()) {  // prefetch target past the last pair (fetched, never tested)
     tris.push_back(HotTri{});
     tris.push_back(HotTri{});
+    pair_boxes.push_back(PairBox{});
   }
   n_spheres = (int)spheres.size();
   if (!spheres.empty()) spheres.push_back(SphereRec{});  // same for the sphere look-ahead

@@ -55,6 +55,23 @@ struct HotTri {
   int32_t pad[2];
 };
 
+// The same world-list triangles once more, per PAIR (a Parallelogram, or a lone Triangle), for the
+// culled form of the list scan (kernels.hip: closest_hit, RUN_TRIS): `PairBox` is read at a
+// wave-uniform index (one s_load_dwordx8): the pair's bounds, padded like the mesh search boxes;
+// `PairPts` is staged in LDS and gathered per lane: the four corners, from which the kernel forms the
+// edges with the same binary32 subtractions the host used for HotTri.
+enum : int32_t { PAIR_SECOND = 1, PAIR_SAME_E2 = 2 };
+struct PairBox {  // 32 B
+  float mn[3], mx[3];
+  int32_t pad[2];
+};
+struct alignas(16) PairPts {  // 64 B
+  float p0[3], p1[3], p2[3], p3[3];  // p3 = p1 + p2 - p0 (parallelogram.cu:13); unused for a lone Triangle
+  int32_t flags;
+  int32_t pad[3];
+};
+constexpr int kLdsPairs = 128;  // at most this many PairPts records are staged in LDS (8 KiB); longer lists use the plain scan
+
 enum MatKind : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_SKY = 4 };
 
 struct MatRec {  // 32 B
@@ -154,6 +171,8 @@ struct SceneDev {
   const Run *runs;
   const SphereRec *spheres;
   const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
+  const PairBox *pair_boxes;  // per pair of `tris` records (index = tri index / 2), one inert record of padding
+  const PairPts *pair_pts;
   const BvhRec *bvhs;
   const BvhNode *nodes;
   const QNode4 *qnodes;
@@ -162,6 +181,8 @@ struct SceneDev {
   const MatRec *mats;
   const TexRec *texs;
   int32_t n_runs, n_mats, n_nodes;
+  int32_t n_pairs;    // pairs in pair_boxes / pair_pts (0: the culled list scan is off)
+  float list_mag;     // largest |coordinate| of the world-list triangles (scales the cull's distance slack)
   int32_t sub_reserve;  // 3 * (deepest search tree) + 3 + kMeshFaceSlack: stack words the wave-wide search keeps free
                         // after a wide step (0 without meshes); see mesh_search
   int32_t unsigned_colours;  // 1: no material colour has its sign bit set (not even -0): then every layer

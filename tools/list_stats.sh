@@ -1,0 +1,17 @@
+#!/bin/bash
+# Diagnostic (GPU box, stats build): how many pairs survive the cull of the world-list scan on C2-like frames.
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+RTMI_LIB_PATH=$ROOT/ray-tracing-cuda_amd/lib/librtmi_stats.so python3 - "${1:-cornell_box}" "${2:-64}" <<'PY'
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "ray-tracing-cuda_amd"))
+import torch, rtmi
+from rtmi import scenes
+name, spp = sys.argv[1], int(sys.argv[2])
+b = rtmi.SceneBuilder(1024); getattr(scenes, name)(b, 1.0) if name != "birthday" else scenes.birthday(b, 1.0, scenes.procedural_earthmap(256, 512)); b.commit()
+R = rtmi.Renderer(b, 1024, 1024, spp, 50).init_rng()
+R.render(); torch.cuda.synchronize()
+out = (C.c_ulonglong * 32)()
+rtmi.lib().rtmi_debug_counters(b.h, out, None)
+rays, wq, bits, iters, crays = out[1], out[4], out[30], out[31], out[3]
+print("rays %d wave_queries %d: candidate pairs per ray %.2f (of %d lane-chunks), wave iterations per query %.2f" % (rays, wq, bits / max(crays, 1), crays, iters / max(wq, 1)))
+PY
