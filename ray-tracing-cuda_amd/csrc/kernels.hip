@@ -762,12 +762,16 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   }
 
   // the ray as the culled list scan wants it: clamped reciprocal, origin shifted by the distance slack
-  V3 cull_inv = splat(0.f), cull_olo = splat(0.f), cull_ohi = splat(0.f);
+  // the ray as the culled list scan wants it: 1/d (the hardware reciprocal will do: the test is conservative by
+  // a margin of 1e-5, not 1e-7), and -(o +- delta)/d per axis, delta = the distance slack of the mesh search
+  V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
   if ((F & F_TRIS) && s_pairs != nullptr) {
-    cull_inv = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
+    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    cull_inv = mk(fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : ix, fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : iy,
+                  fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : iz);
     const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.list_mag);
-    cull_olo = mk(o.x + delta, o.y + delta, o.z + delta);  // against a box's lower planes, moved out by delta ...
-    cull_ohi = mk(o.x - delta, o.y - delta, o.z - delta);  // ... and its upper planes
+    cull_klo = mk(-(o.x + delta) * cull_inv.x, -(o.y + delta) * cull_inv.y, -(o.z + delta) * cull_inv.z);  // lower planes, moved out
+    cull_khi = mk(-(o.x - delta) * cull_inv.x, -(o.y - delta) * cull_inv.y, -(o.z - delta) * cull_inv.z);  // upper planes
   }
 
   for (int ri = 0; ri < sc.n_runs; ri++) {
@@ -808,14 +812,14 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           const f32x8 bx = nxt;
           nxt = load_pair_box(sc.pair_boxes, pair0 + c0 + i + 1);  // (one inert record of padding at the end)
           __builtin_amdgcn_sched_barrier(0);
-          const float t0x = (bx[0] - cull_olo.x) * cull_inv.x, t1x = (bx[3] - cull_ohi.x) * cull_inv.x;
-          const float t0y = (bx[1] - cull_olo.y) * cull_inv.y, t1y = (bx[4] - cull_ohi.y) * cull_inv.y;
-          const float t0z = (bx[2] - cull_olo.z) * cull_inv.z, t1z = (bx[5] - cull_ohi.z) * cull_inv.z;
+          // t = (plane -+ delta - o) / d as one FMA per plane: plane * (1/d) - (o +- delta) * (1/d).  The rounding of
+          // the two products is an error of ~6e-8 of the plane's coordinate in space, far inside delta.
+          const float t0x = __builtin_fmaf(bx[0], cull_inv.x, cull_klo.x), t1x = __builtin_fmaf(bx[3], cull_inv.x, cull_khi.x);
+          const float t0y = __builtin_fmaf(bx[1], cull_inv.y, cull_klo.y), t1y = __builtin_fmaf(bx[4], cull_inv.y, cull_khi.y);
+          const float t0z = __builtin_fmaf(bx[2], cull_inv.z, cull_klo.z), t1z = __builtin_fmaf(bx[5], cull_inv.z, cull_khi.z);
           const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
           const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-          const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), 1e-5f, en));
-          const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), 1e-5f, le));
-          mask |= lo <= hi ? 1u << i : 0u;
+          mask |= fmaxf(lo0, en) <= fminf(hi0, le) ? 1u << i : 0u;
         }
         RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
         while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
