@@ -738,8 +738,8 @@ struct Hit {
 // variants are only entered by tracing lanes and pass true.
 template <uint32_t F>
 __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes,
-                                           const float4 *s_pairs, int *wl, unsigned long long *overflow, V3 o, V3 d,
-                                           bool live
+                                           const float4 *s_pairs, int *ll, int *wl, unsigned long long *overflow, V3 o,
+                                           V3 d, bool live
 #ifdef RTMI_STATS
                                            , MeshStats &st
 #endif
@@ -761,7 +761,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
     sa2 = 2 * sa;
   }
 
-  // the ray as the culled list scan wants it: clamped reciprocal, origin shifted by the distance slack
+  const int lane = (int)(threadIdx.x & 63u);
   // the ray as the culled list scan wants it: 1/d (the hardware reciprocal will do: the test is conservative by
   // a margin of 1e-5, not 1e-7), and -(o +- delta)/d per axis, delta = the distance slack of the mesh search
   V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
@@ -787,7 +787,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       t_to = acc ? ts : t_to;
       win = acc ? make_id(RUN_SKY, 0) : win;
     }
-    if ((F & F_TRIS) && live && run.kind == RUN_TRIS && s_pairs != nullptr) {
+    if ((F & F_TRIS) && run.kind == RUN_TRIS && s_pairs != nullptr) {
       // Culled scan (DESIGN.md "World-list scan").  The reference tests every entry of the list against
       // every ray (hitable_list.cu:11-22); what it RETURNS only depends on the entries whose test can
       // succeed, visited in list order.  Lanes of a wave carry unrelated rays, so no entry can be
@@ -821,43 +821,103 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
           mask |= fmaxf(lo0, en) <= fminf(hi0, le) ? 1u << i : 0u;
         }
+        if (!live) mask = 0u;  // a lane without a ray of its own only helps
         RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
-        while (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
-          RTMI_STAT(st.cull_iters++;)
-          if (mask != 0u) {
-            const int j = __builtin_ctz(mask);
-            mask &= mask - 1u;
-            const float4 *pp = s_pairs + (size_t)(pair0 + c0 + j) * 4;
-            const float4 qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
-            const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
-            const int flags = __float_as_int(qd.x);
-            const int tri = run.first + 2 * (c0 + j);
-            float t = 0.f, u = 0.f, v = 0.f;
-            const V3 e1 = p1 - p0, e2 = p2 - p0;  // utils.cu:54-55, the subtractions scene.hip: make_tri does
-            const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(d, e2), o, d, t_to, t, u, v);
-            {
-              bool acc = hit_a && (!ok || (T)t < t_to);
-              ok = ok || acc;
-              t_to = acc ? (T)t : t_to;
-              win = acc ? make_id(RUN_TRIS, tri) : win;
-              if (F & F_TEX) {
-                bu = acc ? u : bu;
-                bv = acc ? v : bv;
+        {
+          // ---- the candidates of all 64 rays are worked off by all 64 lanes.  A ray comes near 2.2 pairs on
+          // average but the unluckiest of 64 near 6, and a lane-by-lane loop runs as long as that one.  So
+          // (a) every lane writes its ray and one task per candidate pair to LDS (offsets: prefix sum of the
+          // candidate counts by bit planes), (b) lane l takes task l, l + 64, ...: reads that ray and that
+          // pair's corners and runs BOTH triangle tests against the ray's t_to at the start of the chunk,
+          // (c) every lane folds the results of its own candidates in list order with its running t_to:
+          // a test that passed against the older, larger t_to passes now iff its t <= the current one,
+          // which is the only place t_to enters the test (utils.cu:74).
+          constexpr int RW = (F & F_TEX) ? 6 : 2;  // result words per task: t of the two triangles (+ their u, v)
+          int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks;
+          const int cnt = __builtin_popcount(mask);
+          int base = 0;
+#pragma unroll
+          for (int bit = 0; bit < 6; bit++)
+            base += lane_rank(__builtin_amdgcn_ballot_w64(((cnt >> bit) & 1) != 0)) << bit;
+          if (cnt != 0) {
+            int *rr = ll + lane * 8;
+            int w3 = 0, w7 = 0;
+            if (DT) {
+              const double td = (double)t_to;
+              w3 = __double2loint(td), w7 = __double2hiint(td);
+            } else {
+              w3 = __float_as_int((float)t_to);
+            }
+            *reinterpret_cast<int4 *>(rr) = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), w3);
+            *reinterpret_cast<int4 *>(rr + 4) = make_int4(__float_as_int(d.x), __float_as_int(d.y), __float_as_int(d.z), w7);
+          }
+          bool todo = cnt != 0;
+          while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+            RTMI_STAT(st.cull_iters++;)
+            const int lo_t = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
+            const bool now = todo && base + cnt - lo_t <= kListTasks;
+            const int n_now = __builtin_amdgcn_readlane(base + cnt, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo_t;
+            if (now) {  // (a)
+              int k = base - lo_t;
+              for (uint32_t m = mask; m != 0u; m &= m - 1u) tasks[k++] = (lane << 5) | __builtin_ctz(m);
+            }
+            wave_lds_fence();
+            for (int t0 = 0; t0 < n_now; t0 += 64) {  // (b)
+              const int ti = t0 + lane;
+              if (ti < n_now) {
+                const int w = tasks[ti];
+                const int *orr = ll + (w >> 5) * 8;
+                const float4 r0 = *reinterpret_cast<const float4 *>(orr), r1 = *reinterpret_cast<const float4 *>(orr + 4);
+                T t0_to;
+                if (DT) {
+                  t0_to = (T)__hiloint2double(__float_as_int(r1.w), __float_as_int(r0.w));
+                } else {
+                  t0_to = (T)r0.w;
+                }
+                const V3 ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
+                const float4 *pp = s_pairs + (size_t)(pair0 + c0 + (w & 31)) * 4;
+                const float4 qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
+                float ta = 0.f, ua = 0.f, va = 0.f, tb = 0.f, ub = 0.f, vb = 0.f;
+                const V3 e1 = p1 - p0, e2 = p2 - p0;  // utils.cu:54-55, the subtractions scene.hip: make_tri does
+                const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(rd, e2), ro, rd, t0_to, ta, ua, va);
+                bool hit_b = false;
+                if (__float_as_int(qd.x) & PAIR_SECOND) {
+                  const V3 e1b = p2 - p1, e2b = p3 - p1;
+                  hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(rd, e2b), ro, rd, t0_to, tb, ub, vb);
+                }
+                int *res = results + ti * RW;
+                res[0] = hit_a ? __float_as_int(ta) : (int)0xffffffff;  // (a NaN pattern no t can have)
+                res[1] = hit_b ? __float_as_int(tb) : (int)0xffffffff;
+                if (F & F_TEX) {
+                  res[2] = __float_as_int(ua), res[3] = __float_as_int(va), res[4] = __float_as_int(ub), res[5] = __float_as_int(vb);
+                }
               }
             }
-            if (flags & PAIR_SECOND) {  // parallelogram.cu:33: the second triangle is tried only when the first missed
-              const V3 e1b = p2 - p1, e2b = p3 - p1;
-              bool hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(d, e2b), o, d, t_to, t, u, v);
-              hit_b = hit_b && !hit_a;
-              bool acc = hit_b && (!ok || (T)t < t_to);
-              ok = ok || acc;
-              t_to = acc ? (T)t : t_to;
-              win = acc ? make_id(RUN_TRIS, tri + 1) : win;
-              if (F & F_TEX) {
-                bu = acc ? u : bu;
-                bv = acc ? v : bv;
+            wave_lds_fence();
+            if (now) {  // (c)
+              int k = base - lo_t;
+              for (uint32_t m = mask; m != 0u; m &= m - 1u, k++) {
+                const int tri = run.first + 2 * (c0 + __builtin_ctz(m));
+                const int *res = results + k * RW;
+                const int ia = res[0], ib = res[1];
+                const float ta = __int_as_float(ia), tb = __int_as_float(ib);
+                // parallelogram.cu:25-33 with the t_to of THIS moment: the first triangle, else the second
+                const bool hit_a = ia != (int)0xffffffff && (T)ta <= t_to;
+                const bool hit_b = !hit_a && ib != (int)0xffffffff && (T)tb <= t_to;
+                const float t = hit_a ? ta : tb;
+                const bool acc = (hit_a || hit_b) && (!ok || (T)t < t_to);
+                ok = ok || acc;
+                t_to = acc ? (T)t : t_to;
+                win = acc ? make_id(RUN_TRIS, tri + (hit_a ? 0 : 1)) : win;
+                if (F & F_TEX) {
+                  bu = acc ? __int_as_float(hit_a ? res[2] : res[4]) : bu;
+                  bv = acc ? __int_as_float(hit_a ? res[3] : res[5]) : bv;
+                }
               }
+              todo = false;
             }
+            wave_lds_fence();
           }
         }
       }
@@ -981,7 +1041,6 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       // replayed leaf.  If more leaves hold hits than the list has slots, the leaves beyond `cut`
       // are left to a further search pass.
       const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
-      const int lane = (int)(threadIdx.x & 63u);
       int *rr = wl + lane * kMeshRayWords;
       for (int i = 0; i < run.count; i++) {
         BvhRec br;
@@ -1195,6 +1254,8 @@ struct LaunchCfg {
   int32_t mesh_off;    // byte offset of the per-wave mesh-search regions (kMeshWaveWords words each; BVH variants)
   int32_t exclusive;   // 1: while a wave holds an outlier pixel, its other lanes take no new pixels (they work for it)
   int32_t pairs_off;   // byte offset of the staged PairPts records, -1: not staged (plain list scan)
+  int32_t list_off;    // byte offset of the per-wave regions of the shared candidate tests, -1: each lane tests its own
+  int32_t pad2[3];
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
@@ -1225,6 +1286,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.pairs_off);
     for (int w = threadIdx.x; w < sc.n_pairs * 16; w += blockDim.x) dst[w] = src[w];
   }
+  int *ll = nullptr;  // this wave's region for the shared candidate tests of the culled list scan
+  if ((F & F_TRIS) && lc.list_off >= 0)
+    ll = reinterpret_cast<int *>(smem + lc.list_off) +
+         __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * 8 + kListTasks * (1 + ((F & F_TEX) ? 6 : 2)));
   const bool mats_in_lds = lc.lds_mats > 0;
   const bool fast_fold = mats_in_lds && !lc.wide_ids && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
@@ -1369,16 +1434,17 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
               const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
     Hit h = {};
-    if (F & F_BVH)  // every lane goes in: see closest_hit
-      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_pairs, wl, counters + 2, o, d, active
+    const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && s_pairs != nullptr);  // wave-uniform
+    if (all_lanes_in)  // every lane goes in, with or without a ray of its own: see closest_hit
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_pairs, ll, wl, counters + 2, o, d, active
 #ifdef RTMI_STATS
                          , st
 #endif
       );
     RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
     if (active) {
-      if (!(F & F_BVH))
-        h = closest_hit<F>(sc, s_nodes, 0, s_pairs, nullptr, nullptr, o, d, true
+      if (!all_lanes_in)
+        h = closest_hit<F>(sc, s_nodes, 0, s_pairs, nullptr, nullptr, nullptr, o, d, true
 #ifdef RTMI_STATS
                            , st
 #endif
@@ -1792,7 +1858,10 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t poff = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
   const bool cull = (variant & F_TRIS) && sc.n_pairs > 0 && sc.n_pairs <= kLdsPairs && !plain_list_scan();
   lc.pairs_off = cull ? (int32_t)poff : -1;
-  *lds_bytes = poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0);
+  size_t loff = (poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
+  const bool share = cull;  // the culled scan always shares its candidate tests over the wave
+  lc.list_off = share ? (int32_t)loff : -1;
+  *lds_bytes = loff + (share ? (size_t)(threads / 64) * (64 * 8 + kListTasks * (1 + ((variant & F_TEX) ? 6 : 2))) * sizeof(int) : 0);
   return lc;
 }
 

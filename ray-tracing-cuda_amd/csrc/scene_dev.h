@@ -70,6 +70,7 @@ struct alignas(16) PairPts {  // 64 B
   int32_t flags;
   int32_t pad[3];
 };
+constexpr int kListTasks = 192;  // (ray, pair) tasks of the culled list scan that one wave holds in LDS at a time
 constexpr int kLdsPairs = 128;  // at most this many PairPts records are staged in LDS (8 KiB); longer lists use the plain scan
 
 enum MatKind : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_SKY = 4 };
