@@ -1856,7 +1856,7 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t soff = (noff + (size_t)lc.lds_nodes * sizeof(BvhNode) + 15) & ~(size_t)15;
   lc.mesh_off = (int32_t)soff;
   size_t poff = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
-  const bool cull = (variant & F_TRIS) && sc.n_pairs > 0 && sc.n_pairs <= kLdsPairs && !plain_list_scan();
+  const bool cull = (variant & F_TRIS) && sc.n_pairs >= kCullMinPairs && sc.n_pairs <= kLdsPairs && !plain_list_scan();
   lc.pairs_off = cull ? (int32_t)poff : -1;
   size_t loff = (poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
   const bool share = cull;  // the culled scan always shares its candidate tests over the wave

@@ -70,6 +70,7 @@ struct alignas(16) PairPts {  // 64 B
   int32_t flags;
   int32_t pad[3];
 };
+constexpr int kCullMinPairs = 4;  // shorter lists are scanned plainly: the cull and the hand-over through LDS cost more than they save
 constexpr int kListTasks = 192;  // (ray, pair) tasks of the culled list scan that one wave holds in LDS at a time
 constexpr int kLdsPairs = 128;  // at most this many PairPts records are staged in LDS (8 KiB); longer lists use the plain scan
 
