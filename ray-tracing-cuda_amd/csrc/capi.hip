@@ -370,6 +370,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
   if ((rc = upload(s, s->qnodes, &d.qnodes))) return rc;
+  if ((rc = upload(s, s->leaf_paths, &d.leaf_paths))) return rc;
   if ((rc = upload(s, s->faces, &d.faces))) return rc;
   if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;
@@ -379,6 +380,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.list_mag = s->list_mag;
   d.n_mats = (int)s->mat_recs.size();
   d.n_nodes = (int)s->nodes.size();
+  d.n_leaf_paths = (int)s->leaf_paths.size();
   d.sub_reserve = s->sub_depth > 0 ? 3 * s->sub_depth + 3 + kMeshFaceSlack : 0;
   d.unsigned_colours = 1;
   for (const MatRec &m : s->mat_recs) {
@@ -579,7 +581,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   hipStream_t st = (hipStream_t)stream;
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
-  const uint32_t *d_order = nullptr, *d_sparse = nullptr;
+  SchedPlan plan;
   const int probe_spp = 2;
   const bool many_tiles = (int64_t)d.local_tiles * 64 > (int64_t)blocks * threads;
   if (tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
@@ -605,22 +607,22 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_rays = p_states + n * RTMI_STATE_WORDS;
     uint32_t *p_cost = p_rays + n;
     uint32_t *p_order = p_cost + nt;
-    uint32_t *p_max = p_order + nt;
+    uint32_t *p_meta = p_order + nt;  // 16 words (launch_tile_order)
     HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
     probe.spp = probe_spp;
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
-    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, nullptr, nullptr, true,
-                          blocks, threads, tune, st));
+    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, SchedPlan(), true, blocks,
+                          threads, tune, st));
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
-    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_max, p_order, sparse_cap, tune.outlier_x10, st));
-    d_order = p_order;
-    d_sparse = p_max + 1;
+    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, sparse_cap, tune.outlier_x10, st));
+    plan.tile_order = p_order;
+    plan.sparse_items = p_meta + 1;
   }
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
-                        s->d_counters, d_order, d_sparse, false, blocks, threads, tune, st));
+                        s->d_counters, plan, false, blocks, threads, tune, st));
   return RTMI_OK;
 }
 

@@ -31,14 +31,18 @@ struct RenderTuning {
   int exclusive;      // 1: a wave holding an outlier pixel takes no other new pixels (its lanes work for it)
   int outlier_x10;    // a tile is an outlier from this many tenths of the mean tile cost
 };
+// What the scheduler's probe pass leaves for the real pass (device pointers, all optional).
+struct SchedPlan {
+  const uint32_t *tile_order = nullptr;    // local tiles, most expensive first
+  const uint32_t *sparse_items = nullptr;  // one word: leading work items handed to every sparse_stride-th lane only
+};
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
-                         uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, const RenderTuning &tune,
-                         hipStream_t stream);
+                         uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan, bool probe,
+                         int blocks, int threads, const RenderTuning &tune, hipStream_t stream);
 // Tiles sorted by descending cost (sum of 64 ray counts each); d_cost/d_order hold n_tiles words,
-// d_max two (the largest cost, the sparse item count).
+// d_meta 16: [0] the largest tile cost, [1] the sparse item count.
 // sparse_cap: work items the grid holds at one pixel per tune.sparse_stride lanes (a multiple of 64).
-hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
+hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t sparse_cap, int outlier_x10, hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);

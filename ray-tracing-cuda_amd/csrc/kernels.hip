@@ -487,14 +487,20 @@ __device__ __forceinline__ unsigned long long stat_now() {
   return t;
 }
 #define RTMI_STAT(x) x
-#if RTMI_STATS >= 2
+#if RTMI_STATS == 2
 #define RTMI_STAT2(x) x  // per-step stamps (a stamp costs several hundred cycles: they distort what they measure)
 #else
 #define RTMI_STAT2(x)
 #endif
+#if RTMI_STATS == 3
+#define RTMI_STAT3(x) x  // replay sections instead of the per-step stamps: [5] order + offsets, [6] (a), [7] (b), [8] (c)
+#else
+#define RTMI_STAT3(x)
+#endif
 #else
 #define RTMI_STAT(x)
 #define RTMI_STAT2(x)
+#define RTMI_STAT3(x)
 #endif
 
 // One search pass for the lanes with `need`: afterwards every such lane's record holds, per
@@ -550,7 +556,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
       wave_lds_fence();
       unsigned pend = 0u;  // bit j: face first + j passed the test ...
       float pt0 = 0.f, pt1 = 0.f, pt2 = 0.f, pt3 = 0.f;  // ... with this t ...
-      float po0 = 0.f, po1 = 0.f, po2 = 0.f, po3 = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f, pc3 = 0.f;  // ... orig, code
+      float po0 = 0.f, po1 = 0.f, po2 = 0.f, po3 = 0.f, pc0 = 0.f, pc1 = 0.f, pc2 = 0.f, pc3 = 0.f;  // ... orig, leaf
       const int owner = (int)((unsigned)e >> 26), fcnt = e & 7;
       int first = (e >> 3) & (kMeshMaxFaces - 1);
       int *rr = wl + owner * kMeshRayWords;
@@ -573,7 +579,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
 #if defined(RTMI_ABLATE) && RTMI_ABLATE == 2
           th = th && t < -1.f;  // never
 #endif
-          if (th) pend = 1u, pt0 = t, po0 = c.y, pc0 = c.z;
+          if (th) pend = 1u, pt0 = t, po0 = c.y, pc0 = c.w;
         }
       } else if (mine) {
         const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r1 = *reinterpret_cast<const float4 *>(rr + 4);
@@ -602,10 +608,10 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
 #endif
                 if (th) {
                   pend |= 1u << (half * 2 + fi);
-                  if (half * 2 + fi == 0) pt0 = t, po0 = c.y, pc0 = c.z;
-                  if (half * 2 + fi == 1) pt1 = t, po1 = c.y, pc1 = c.z;
-                  if (half * 2 + fi == 2) pt2 = t, po2 = c.y, pc2 = c.z;
-                  if (half * 2 + fi == 3) pt3 = t, po3 = c.y, pc3 = c.z;
+                  if (half * 2 + fi == 0) pt0 = t, po0 = c.y, pc0 = c.w;
+                  if (half * 2 + fi == 1) pt1 = t, po1 = c.y, pc1 = c.w;
+                  if (half * 2 + fi == 2) pt2 = t, po2 = c.y, pc2 = c.w;
+                  if (half * 2 + fi == 3) pt3 = t, po3 = c.y, pc3 = c.w;
                 }
               }
             }
@@ -665,9 +671,11 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
           NodeFrame nf;
           node_frame(w0, r0, r2, mag, nf);
           const int sh = 8 * c;
-          hit = child != -1 && child_box_hit(nf, (float)((w1.x >> sh) & 0xffu), (float)((w1.y >> sh) & 0xffu),
-                                             (float)((w1.z >> sh) & 0xffu), (float)((w1.w >> sh) & 0xffu),
-                                             (float)((w2.x >> sh) & 0xffu), (float)((w2.y >> sh) & 0xffu), lo0, r2.w);
+          // (tested whether or not the slot is used: the child word must not gate the other loads)
+          const bool bh = child_box_hit(nf, (float)((w1.x >> sh) & 0xffu), (float)((w1.y >> sh) & 0xffu),
+                                        (float)((w1.z >> sh) & 0xffu), (float)((w1.w >> sh) & 0xffu),
+                                        (float)((w2.x >> sh) & 0xffu), (float)((w2.y >> sh) & 0xffu), lo0, r2.w);
+          hit = (child != -1) & bh;
         }
         RTMI_STAT2(const unsigned long long tn2 = stat_now(); st.cyc[5] += tn1 - tn0; st.cyc[6] += tn2 - tn1;)
         const bool pn = hit && child >= 0, pf = hit && child < 0;
@@ -737,8 +745,8 @@ struct Hit {
 // lanes); a lane that is not tracing passes live = false and gets an unused result.  The other
 // variants are only entered by tracing lanes and pass true.
 template <uint32_t F>
-__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes,
-                                           const float4 *s_pairs, int *ll, int *wl, unsigned long long *overflow, V3 o,
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, const int *s_paths,
+                                           int lds_paths, const float4 *s_pairs, int *ll, int *wl, unsigned long long *overflow, V3 o,
                                            V3 d, bool live
 #ifdef RTMI_STATS
                                            , MeshStats &st
@@ -805,6 +813,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         const int nc = run.count - c0 < 32 ? run.count - c0 : 32;
         const float hi0 = (float)t_to * 1.0001f + 1e-6f;
         uint32_t mask = 0u;
+        RTMI_STAT2(const unsigned long long tc0 = stat_now();)
         f32x8 nxt = load_pair_box(sc.pair_boxes, pair0 + c0);
         for (int i = 0; i < nc; i++) {
           __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the plain scan below
@@ -822,6 +831,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           mask |= fmaxf(lo0, en) <= fminf(hi0, le) ? 1u << i : 0u;
         }
         if (!live) mask = 0u;  // a lane without a ray of its own only helps
+        RTMI_STAT2(const unsigned long long tc1 = stat_now(); st.cyc[5] += tc1 - tc0;)
         RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
         {
           // ---- the candidates of all 64 rays are worked off by all 64 lanes.  A ray comes near 2.2 pairs on
@@ -895,6 +905,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
               }
             }
             wave_lds_fence();
+            RTMI_STAT2(const unsigned long long tc2 = stat_now();)
             if (now) {  // (c)
               int k = base - lo_t;
               for (uint32_t m = mask; m != 0u; m &= m - 1u, k++) {
@@ -918,8 +929,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
               todo = false;
             }
             wave_lds_fence();
+            RTMI_STAT2(st.cyc[7] += stat_now() - tc2;)
           }
         }
+        RTMI_STAT2(st.cyc[6] += stat_now() - tc1;)  // (a) + (b) + (c); [7] is (c) alone
       }
     } else if ((F & F_TRIS) && live && run.kind == RUN_TRIS) {
       // Plain scan (lists too long for the LDS staging of the culled one).
@@ -1048,7 +1061,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           const i32x8 bw = load_bvh_rec(sc.bvhs, run.first + i);  // wave-uniform: scalar load
           br.root = bw[0], br.mat = bw[1], br.has_uv = bw[2], br.face_base = bw[3], br.sub_root = bw[4];
           br.mag = __int_as_float(bw[5]);
-          br.ref_depth = bw[6];
+          br.ref_depth = bw[6], br.path_base = bw[7];
         }
         T bt_to = t_to;
         bool bhit = false;
@@ -1074,80 +1087,76 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           // ---- (2) replay the listed leaves in the reference's visiting order.  The box tests are
           // spread over the wave: AABB::Hit(box, [t_from, T]) is `crossing time <= T` with a crossing time
           // that does not depend on T (aabb_crossing_time), so (a) every lane with listed leaves writes one
-          // task per (leaf, level) of their paths into the search's (now empty) stack, (b) all 64 lanes
-          // work the tasks off, whoever's they are, (c) each lane walks its leaves with the running t_to,
-          // looking the crossing times up.  A lane whose leaves do not fit next to the others' waits for
-          // the next round.
+          // word per leaf (its lane, the leaf's row in the mesh's path table) into the search's (now empty)
+          // stack, (b) all 64 lanes work off the (leaf, level) pairs, whoever's they are: node from the path
+          // table, its box, that ray, the crossing time, (c) each lane walks its leaves with the running
+          // t_to, looking the crossing times up.  A lane whose leaves do not fit next to the others' waits
+          // for the next round.
           RTMI_STAT(const unsigned long long tr0 = stat_now(); (void)tr0;)
           uint32_t cut = kCodeNone;
           int cnt = 0;
-          if (need) cnt = rr[12], cut = (uint32_t)rr[13];
-          // my leaves in visiting order: slot numbers packed two bits each
-          int ord = 0, nleaf = 0;
-          {
-            bool have_last = false;
-            uint32_t last = 0u;
-            for (int k = 0; k < cnt; k++) {
-              int sel = -1;
-              uint32_t code = 0xffffffffu;
+          int4 hs[kHitSlots];  // my entries: leaf, face, t
 #pragma unroll
-              for (int j = 0; j < kHitSlots; j++) {
-                if (j < cnt) {
-                  const uint32_t cj = (uint32_t)rr[16 + j * kHitWords];
-                  if ((!have_last || cj > last) && cj < cut && cj <= code) code = cj, sel = j;
-                }
-              }
-              if (sel < 0) break;  // the rest was pushed beyond `cut`
-              have_last = true, last = code;
-              ord |= sel << (2 * nleaf);
-              nleaf++;
-            }
+          for (int j = 0; j < kHitSlots; j++) hs[j] = make_int4((int)kCodeNone, 0, 0, 0);
+          if (need) {
+            const int4 head = *reinterpret_cast<const int4 *>(rr + 12);
+            cnt = head.x, cut = (uint32_t)head.y;
+            const int4 wa = *reinterpret_cast<const int4 *>(rr + 16), wb = *reinterpret_cast<const int4 *>(rr + 20),
+                       wc = *reinterpret_cast<const int4 *>(rr + 24);
+            const int4 e4[kHitSlots] = {make_int4(wa.x, wa.y, wa.z, 0), make_int4(wa.w, wb.x, wb.y, 0),
+                                        make_int4(wb.z, wb.w, wc.x, 0), make_int4(wc.y, wc.z, wc.w, 0)};
+#pragma unroll
+            for (int j = 0; j < kHitSlots; j++)
+              if (j < cnt && (uint32_t)e4[j].x < cut) hs[j] = e4[j];  // (the rest was pushed beyond `cut`: next pass)
           }
+          // ... in visiting order = by ascending leaf ordinal (never kCodeNone): a five-exchange network
+#define RTMI_ORDER(A, B)                                        \
+  {                                                             \
+    const bool sw = (uint32_t)hs[B].x < (uint32_t)hs[A].x;      \
+    const int4 lo_ = sw ? hs[B] : hs[A], hi_ = sw ? hs[A] : hs[B]; \
+    hs[A] = lo_, hs[B] = hi_;                                   \
+  }
+          RTMI_ORDER(0, 1) RTMI_ORDER(2, 3) RTMI_ORDER(0, 2) RTMI_ORDER(1, 3) RTMI_ORDER(1, 2)
+#undef RTMI_ORDER
+          int nleaf = 0;
+#pragma unroll
+          for (int j = 0; j < kHitSlots; j++) nleaf += (uint32_t)hs[j].x != kCodeNone ? 1 : 0;
           const int depth_r = br.ref_depth;
-          const int ntask = nleaf * depth_r;
+          const int log_d = depth_r < 8 ? 3 : depth_r < 16 ? 4 : 5;  // a leaf's row: its path code + the crossing times, 8, 16 or 32 words
+          const int rows_max = (kMeshStackWords - 64) >> log_d;
           // exclusive prefix sum of nleaf (0..4) over the wave, bit plane by bit plane: no LDS round trips
-          const int base = depth_r * (lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 1) != 0)) +
-                                      2 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 2) != 0)) +
-                                      4 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 4) != 0)));
-          int *tasks = wl + 64 * kMeshRayWords;
-          bool todo = ntask > 0;
+          const int base = lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 1) != 0)) +
+                           2 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 2) != 0)) +
+                           4 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 4) != 0));
+          int *leaves = wl + 64 * kMeshRayWords;  // [64] one word per listed leaf of this round
+          int *times = leaves + 64;                // rows of crossing times
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 4
+          bool todo = false;  // (diagnostic: no replay, nearest listed hit)
+#else
+          bool todo = nleaf > 0 && depth_r > 0;
+#endif
+          RTMI_STAT3(unsigned long long tr1 = stat_now(); st.cyc[5] += tr1 - ts1;)
           while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
             const int lo = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
-            const bool now = todo && base + ntask - lo <= kMeshStackWords;
-            const int n_now = __builtin_amdgcn_readlane(base + ntask, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo;
-            // (a) tasks: [lane : 6][node : 26], all-ones node = past the leaf
-            if (now) {
-              for (int k = 0; k < nleaf; k++) {
-                const uint32_t code = (uint32_t)rr[16 + ((ord >> (2 * k)) & 3) * kHitWords];
-                int ni = br.root;
-                bool past = false;
-                for (int lvl = 1; lvl <= depth_r; lvl++) {
-                  if (!past) {
-                    int left, right;
-                    if (ni < lds_nodes) {
-                      left = s_nodes[ni].left, right = s_nodes[ni].right;
-                    } else {
-                      left = sc.nodes[ni].left, right = sc.nodes[ni].right;
-                    }
-                    if (right < 0) {
-                      past = true;
-                    } else {
-                      ni = (code & (0x80000000u >> (lvl - 1))) ? right : left;
-                    }
-                  }
-                  tasks[base - lo + k * depth_r + lvl - 1] = (lane << 26) | (past ? (kMeshMaxNodes - 1) : ni);
-                }
-              }
+            const bool now = todo && base + nleaf - lo <= rows_max;
+            const int n_rows = __builtin_amdgcn_readlane(base + nleaf, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo;
+            if (now) {  // (a)
+#pragma unroll
+              for (int k = 0; k < kHitSlots; k++)
+                if (k < nleaf) leaves[base - lo + k] = (lane << 26) | hs[k].x;
             }
             wave_lds_fence();
-            // (b) crossing times, one task per lane and round
+            RTMI_STAT3(const unsigned long long tr2 = stat_now(); st.cyc[6] += tr2 - tr1;)
+            // (b) crossing times, one (leaf, level) per lane and round
+            const int n_now = n_rows << log_d;
             for (int t0 = 0; t0 < n_now; t0 += 64) {
-              const int t = t0 + lane;
-              if (t < n_now) {
-                const int w = tasks[t];
-                const int ni = w & (kMeshMaxNodes - 1);
-                float m = __int_as_float(0xffffffff);  // marker: past the leaf
-                if (ni != kMeshMaxNodes - 1) {
+              const int t = t0 + lane, lvl = t & ((1 << log_d) - 1);  // word 0 of a row: the leaf's path code
+              if (t < n_now && lvl <= depth_r) {
+                const int w = leaves[t >> log_d];
+                const int pi = br.path_base + (w & (kMeshMaxNodes - 1)) * (depth_r + 1) + lvl;
+                const int ni = pi < lds_paths ? s_paths[pi] : sc.leaf_paths[pi];
+                float m = __int_as_float(lvl == 0 ? ni : (int)0xffffffff);  // marker: past the leaf
+                if (lvl != 0 && ni >= 0) {
                   const int *orr = wl + (int)((unsigned)w >> 26) * kMeshRayWords;
                   const float4 r0 = *reinterpret_cast<const float4 *>(orr + 0), r1 = *reinterpret_cast<const float4 *>(orr + 4);
                   BvhNode nd;
@@ -1156,57 +1165,81 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                   } else {
                     nd = sc.nodes[ni];
                   }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 5
+                  m = nd.mn[0] * r0.x + r1.x;  // (diagnostic: the loads without the arithmetic)
+#else
                   m = aabb_crossing_time(nd, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+#endif
                 }
-                tasks[t] = __float_as_int(m);
+                times[t] = __float_as_int(m);
               }
             }
             wave_lds_fence();
+            RTMI_STAT3(const unsigned long long tr3 = stat_now(); st.cyc[7] += tr3 - tr2;)
             // (c) the walk of bvh.cuh:123-158 over my leaves
-            if (now) {
-              for (int k = 0; k < nleaf; k++) {
-                const int sel = (ord >> (2 * k)) & 3;
-                const uint32_t code = (uint32_t)rr[16 + sel * kHitWords];
-                const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
-                uint32_t bits = shared ? entered & (0xffffffffu << (32 - shared)) : 0u;
-                bool ent = true;
-                for (int lvl = 1; lvl <= depth_r; lvl++) {
-                  const int mi = tasks[base - lo + k * depth_r + lvl - 1];
-                  if (mi == (int)0xffffffff) break;  // the node above was the leaf, and every box on the way was entered
-                  const uint32_t bit = 0x80000000u >> (lvl - 1);
-                  if (lvl <= shared) {
-                    ent = (bits & bit) != 0u;
-                  } else {
+            // (c) the walk of bvh.cuh:123-158 over my leaves, without branches: per leaf one bit per level,
+            // left-aligned like the path code -- `valid` the levels of its path (a prefix), `pass` the levels whose
+            // box is entered: as the previous leaf found it where the two paths coincide, by `crossing time <=
+            // t_to` below.  The walk stops at the first level that is not entered; the leaf's faces count iff
+            // there is none.
+            if (__builtin_amdgcn_ballot_w64(now) != 0ull) {
+#pragma unroll
+              for (int k = 0; k < kHitSlots; k++) {
+                if (__builtin_amdgcn_ballot_w64(now && k < nleaf) == 0ull) break;  // wave-uniform
+                const bool mine = now && k < nleaf;
+                const int *row = times + (mine ? (base - lo + k) << log_d : 0);
+                uint32_t code = 0u, valid = 0u, below = 0u;
+                for (int c = 0; c <= depth_r; c += 8) {  // wave-uniform trip count
+                  const int4 ma = *reinterpret_cast<const int4 *>(row + c), mb = *reinterpret_cast<const int4 *>(row + c + 4);
+                  const int mv[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+                  if (c == 0) code = (uint32_t)ma.x;
+#pragma unroll
+                  for (int j = 0; j < 8; j++) {
+                    const uint32_t bit = 0x80000000u >> ((c + j - 1) & 31);  // level c + j (>= 1)
+                    const bool in_row = c + j >= 1 && c + j <= depth_r;
+                    valid |= in_row && mv[j] != (int)0xffffffff ? bit : 0u;
 #if defined(RTMI_ABLATE) && RTMI_ABLATE == 1
-                    ent = true;
+                    below |= in_row ? bit : 0u;
 #else
-                    ent = (T)__int_as_float(mi) <= bt_to;
+                    below |= in_row && (T)__int_as_float(mv[j]) <= bt_to ? bit : 0u;  // (the marker is a NaN: false)
 #endif
-                    if (ent) bits |= bit;
                   }
-                  if (!ent) break;
                 }
-                have_prev = true;
-                prev_code = code;
-                entered = bits;
-                if (ent) {
-                  const T tj = (T)__int_as_float(rr[16 + sel * kHitWords + 2]);
-                  if (tj <= bt_to) {
+                const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
+                const uint32_t common = shared ? 0xffffffffu << (32 - shared) : 0u;
+                const uint32_t pass = (entered & common) | (below & ~common);
+                const uint32_t fail = valid & ~pass;
+                const int upto = fail ? __clz((int)fail) : __popc(valid);  // levels entered before the walk stopped
+                const uint32_t walked = upto ? 0xffffffffu << (32 - upto) : 0u;
+                const uint32_t bits = (entered & common) | (walked & ~common);
+                if (mine) {
+                  have_prev = true;
+                  prev_code = code;
+                  entered = bits;
+                  const T tj = (T)__int_as_float(hs[k].z);
+                  if (fail == 0u && tj <= bt_to) {
                     bt_to = tj;
                     bhit = true;
-                    bface = rr[16 + sel * kHitWords + 1];
+                    bface = hs[k].y;
                   }
                 }
               }
-              todo = false;
+              if (now) todo = false;
             }
             wave_lds_fence();
+            RTMI_STAT3(tr1 = stat_now(); st.cyc[8] += tr1 - tr3;)
           }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 4
+          if (nleaf > 0) {
+#else
           if (nleaf > 0 && depth_r == 0) {  // the root is the only leaf: nothing to test (its box never is)
-            for (int k = 0; k < nleaf; k++) {
-              const int sel = (ord >> (2 * k)) & 3;
-              const T tj = (T)__int_as_float(rr[16 + sel * kHitWords + 2]);
-              if (tj <= bt_to) bt_to = tj, bhit = true, bface = rr[16 + sel * kHitWords + 1];
+#endif
+#pragma unroll
+            for (int k = 0; k < kHitSlots; k++) {
+              if (k < nleaf) {
+                const T tj = (T)__int_as_float(hs[k].z);
+                if (tj <= bt_to) bt_to = tj, bhit = true, bface = hs[k].y;
+              }
             }
           }
           need = need && cut != kCodeNone;  // leaves were deferred: search again from `cut` on
@@ -1255,7 +1288,9 @@ struct LaunchCfg {
   int32_t exclusive;   // 1: while a wave holds an outlier pixel, its other lanes take no new pixels (they work for it)
   int32_t pairs_off;   // byte offset of the staged PairPts records, -1: not staged (plain list scan)
   int32_t list_off;    // byte offset of the per-wave regions of the shared candidate tests, -1: each lane tests its own
-  int32_t pad2[3];
+  int32_t paths_off;   // byte offset of the staged leaf-path words
+  int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
+  int32_t pad2[1];
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
@@ -1302,6 +1337,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.nodes_off);
     for (int w = threadIdx.x; w < lc.lds_nodes * 8; w += blockDim.x) dst[w] = src[w];
   }
+  const int *s_paths = reinterpret_cast<const int *>(smem + lc.paths_off);
+  if ((F & F_BVH) && lc.lds_paths > 0) {
+    int *dst = reinterpret_cast<int *>(smem + lc.paths_off);
+    for (int w = threadIdx.x; w < lc.lds_paths; w += blockDim.x) dst[w] = sc.leaf_paths[w];
+  }
   __syncthreads();
 
   const int64_t n_items = fr.items;
@@ -1310,7 +1350,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // per-lane pixel state
   int64_t q = 0;
   int pi = 0, pj = 0, k = 0;
-  bool has_px = false, done = false, active = false, heavy = false;
+  bool has_px = false, done = false, active = false;
+  bool heavy = false;  // a pixel of the queue's sparse head (see below)
   V3 color = splat(0.f);
   uint32_t rays = 0;
   unsigned long long ray_total = 0;
@@ -1334,34 +1375,56 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // with full waves.
   unsigned long long sparse_limit = 0ull;
   if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
+  auto take_item = [&](int64_t item) -> bool {  // false: ragged-tile padding (or nothing to sample), written as black
+    q = item;
+    int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
+    if (idx < 0 || fr.spp <= 0) {
+      out[q * 3 + 0] = 0.f, out[q * 3 + 1] = 0.f, out[q * 3 + 2] = 0.f;
+      if (ray_counts) ray_counts[q] = 0;
+      return false;
+    }
+    pi = (int)(idx / fr.width);
+    pj = (int)(idx % fr.width);
+    rng.d = states[0 * n_items + q];
+    rng.v0 = states[1 * n_items + q];
+    rng.v1 = states[2 * n_items + q];
+    rng.v2 = states[3 * n_items + q];
+    rng.v3 = states[4 * n_items + q];
+    rng.v4 = states[5 * n_items + q];
+    k = 0;
+    rays = 0;
+    color = splat(0.f);
+    has_px = true;
+    return true;
+  };
 
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_now();)
   for (;;) {
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
     // -------------------------------------------------------- sample / pixel bookkeeping
+    if (!active && !done && has_px && k >= fr.spp) {
+      V3 c = color;
+      if (fr.post) {  // ray_tracing.cu:78-83
+        c = c / (float)fr.spp;
+        c = mk(clamp1(c.x, 0.f, 1.f), clamp1(c.y, 0.f, 1.f), clamp1(c.z, 0.f, 1.f));
+        c = mk(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
+      }
+      out[q * 3 + 0] = c.x;
+      out[q * 3 + 1] = c.y;
+      out[q * 3 + 2] = c.z;
+      if (ray_counts) ray_counts[q] = rays;
+      ray_total += rays;
+      states[0 * n_items + q] = rng.d;
+      states[1 * n_items + q] = rng.v0;
+      states[2 * n_items + q] = rng.v1;
+      states[3 * n_items + q] = rng.v2;
+      states[4 * n_items + q] = rng.v3;
+      states[5 * n_items + q] = rng.v4;
+      has_px = false;
+    }
     const bool wave_heavy = (F & F_BVH) && lc.exclusive &&
                             __builtin_amdgcn_ballot_w64(has_px && heavy && (active || k < fr.spp)) != 0ull;
     if (!active && !done) {
-      if (has_px && k >= fr.spp) {
-        V3 c = color;
-        if (fr.post) {  // ray_tracing.cu:78-83
-          c = c / (float)fr.spp;
-          c = mk(clamp1(c.x, 0.f, 1.f), clamp1(c.y, 0.f, 1.f), clamp1(c.z, 0.f, 1.f));
-          c = mk(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
-        }
-        out[q * 3 + 0] = c.x;
-        out[q * 3 + 1] = c.y;
-        out[q * 3 + 2] = c.z;
-        if (ray_counts) ray_counts[q] = rays;
-        ray_total += rays;
-        states[0 * n_items + q] = rng.d;
-        states[1 * n_items + q] = rng.v0;
-        states[2 * n_items + q] = rng.v1;
-        states[3 * n_items + q] = rng.v2;
-        states[4 * n_items + q] = rng.v3;
-        states[5 * n_items + q] = rng.v4;
-        has_px = false;
-      }
       while (!has_px && !done) {
         if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (uint32_t)(lc.sparse_stride - 1)) != 0) {
           if (wave_heavy) break;  // this wave is busy with an outlier pixel: stay a helper
@@ -1370,31 +1433,14 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           // and the mesh search runs in its cooperative mode
           if (__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sparse_limit) break;
         }
-        unsigned long long nq = atomicAdd(&counters[0], 1ull);
+        const unsigned long long nq = atomicAdd(&counters[0], 1ull);
         if ((int64_t)nq >= n_items) {
           done = true;
           break;
         }
-        q = (int64_t)nq;
-        if (lc.tile_order) q = (int64_t)lc.tile_order[nq >> 6] * 64 + (int64_t)(nq & 63);
-        int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
-        if (idx < 0 || fr.spp <= 0) {  // ragged-tile padding (or nothing to sample)
-          out[q * 3 + 0] = 0.f, out[q * 3 + 1] = 0.f, out[q * 3 + 2] = 0.f;
-          if (ray_counts) ray_counts[q] = 0;
-          continue;
-        }
-        pi = (int)(idx / fr.width);
-        pj = (int)(idx % fr.width);
-        rng.d = states[0 * n_items + q];
-        rng.v0 = states[1 * n_items + q];
-        rng.v1 = states[2 * n_items + q];
-        rng.v2 = states[3 * n_items + q];
-        rng.v3 = states[4 * n_items + q];
-        rng.v4 = states[5 * n_items + q];
-        k = 0;
-        rays = 0;
-        color = splat(0.f);
-        has_px = true;
+        int64_t item = (int64_t)nq;
+        if (lc.tile_order) item = (int64_t)lc.tile_order[nq >> 6] * 64 + (int64_t)(nq & 63);
+        if (!take_item(item)) continue;
         heavy = nq < sparse_limit;
       }
       if (has_px) {
@@ -1436,7 +1482,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     Hit h = {};
     const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && s_pairs != nullptr);  // wave-uniform
     if (all_lanes_in)  // every lane goes in, with or without a ray of its own: see closest_hit
-      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_pairs, ll, wl, counters + 2, o, d, active
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, wl, counters + 2, o, d, active
 #ifdef RTMI_STATS
                          , st
 #endif
@@ -1444,7 +1490,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
     if (active) {
       if (!all_lanes_in)
-        h = closest_hit<F>(sc, s_nodes, 0, s_pairs, nullptr, nullptr, nullptr, o, d, true
+        h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, o, d, true
 #ifdef RTMI_STATS
                            , st
 #endif
@@ -1516,6 +1562,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           }
           const MatRec m = mats_in_lds ? s_mats[mat] : sc.mats[mat];
           V3 rgb = mk(m.r, m.g, m.b);
+          RTMI_STAT2(if (!(F & F_BVH)) { const unsigned long long tsa = stat_now();  // (divergent code: first active lane reports)
+            if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][9] += tsa - tq2; })
           if (F & F_TEX) {
             if (m.tex >= 0 && (m.kind == MAT_LAMBERTIAN || m.kind == MAT_LIGHT)) {
               // image_texture.cu:11-13: v = 1.0 - v in double, then float coordinates
@@ -1576,6 +1624,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           }
         }
       }
+      RTMI_STAT2(if (!(F & F_BVH)) { const unsigned long long tsb = stat_now();
+        if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][10] += tsb - tq2; })
       if (ended) {
         // ray_tracing.cu:50-52 with emitted == 0 on every stored layer: result = emitted +
         // attenuation * result, deepest layer first.  The addition only matters for a product of -0,
@@ -1644,7 +1694,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     atomicAdd(&counters[31], st.cull_iters);
     atomicAdd(&counters[3], st.cull_rays);
     const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wid < 16384u) {
+    if (!(F & F_BVH) && wid < 16384u) {
+      atomicAdd(&counters[25], g_wave_stats[wid][9]);
+      atomicAdd(&counters[6], g_wave_stats[wid][10]);
+      g_wave_stats[wid][9] = 0, g_wave_stats[wid][10] = 0;
+    } else if (wid < 16384u) {
       g_wave_stats[wid][0] = life;
       for (int i = 0; i < 9; i++) g_wave_stats[wid][1 + i] = st.cyc[i];
       g_wave_stats[wid][10] = wave_queries, g_wave_stats[wid][11] = st.node_steps, g_wave_stats[wid][12] = st.face_steps;
@@ -1771,13 +1825,13 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
   }
 }
 
-hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_max,
+hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t sparse_cap, int outlier_x10, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(d_max, 0, sizeof(uint32_t), stream);
+  hipError_t e = hipMemsetAsync(d_meta, 0, 16 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
-                     d_max);
-  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_max, n_tiles, d_order, d_max + 1,
+                     d_meta);
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_meta, n_tiles, d_order, d_meta + 1,
                      sparse_cap, (uint32_t)outlier_x10);
   return hipGetLastError();
 }
@@ -1853,7 +1907,10 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t noff = (off + stack + 15) & ~(size_t)15;
   lc.nodes_off = (int32_t)noff;
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
-  size_t soff = (noff + (size_t)lc.lds_nodes * sizeof(BvhNode) + 15) & ~(size_t)15;
+  size_t paoff = (noff + (size_t)lc.lds_nodes * sizeof(BvhNode) + 15) & ~(size_t)15;
+  lc.paths_off = (int32_t)paoff;
+  lc.lds_paths = (variant & F_BVH) ? (sc.n_leaf_paths < kLdsPaths ? sc.n_leaf_paths : kLdsPaths) : 0;
+  size_t soff = (paoff + (size_t)lc.lds_paths * sizeof(int32_t) + 15) & ~(size_t)15;
   lc.mesh_off = (int32_t)soff;
   size_t poff = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
   const bool cull = (variant & F_TRIS) && sc.n_pairs >= kCullMinPairs && sc.n_pairs <= kLdsPairs && !plain_list_scan();
@@ -1867,13 +1924,12 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
 
 template <uint32_t F>
 static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
-                                  uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                                  const uint32_t *d_sparse_items, bool probe, int blocks, int threads,
-                                  const RenderTuning &tune, hipStream_t stream) {
+                                  uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan,
+                                  bool probe, int blocks, int threads, const RenderTuning &tune, hipStream_t stream) {
   size_t lds = 0;
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
-  lc.tile_order = d_tile_order;
-  lc.sparse_items = d_sparse_items;
+  lc.tile_order = plan.tile_order;
+  lc.sparse_items = plan.sparse_items;
   lc.sparse_stride = tune.sparse_stride;
   lc.exclusive = tune.exclusive;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
@@ -1933,13 +1989,12 @@ int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, i
 }
 
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
-                         uint32_t *d_ray_counts, unsigned long long *d_counters, const uint32_t *d_tile_order,
-                         const uint32_t *d_sparse_items, bool probe, int blocks, int threads, const RenderTuning &tune,
-                         hipStream_t stream) {
+                         uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan, bool probe,
+                         int blocks, int threads, const RenderTuning &tune, hipStream_t stream) {
 #define X(V) \
   if (variant == (uint32_t)(V)) \
-    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, d_tile_order, d_sparse_items, probe, \
-                                blocks, threads, tune, stream);
+    return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, plan, probe, blocks, threads, tune, \
+                                stream);
   RTMI_FOR_EACH_VARIANT(X)
 #undef X
   return hipErrorInvalidValue;

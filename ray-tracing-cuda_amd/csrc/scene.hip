@@ -153,6 +153,7 @@ struct FacePts {
   float uv[6];
   int orig;
   uint32_t code;
+  int leaf;  // ordinal of the reference leaf in visiting order
 };
 
 // ---- the search tree (DESIGN.md "Mesh queries"): binned-SAH binary tree over the faces, leaves
@@ -373,8 +374,11 @@ static int build_subtree(std::vector<QNode4> &qn, std::vector<FacePts> &fp, int 
 // a stable sort; one stable sort of the whole range reproduces it.  (thrust::sort
 // does not promise an order for equal keys; this build fixes it as stable.)
 // Every face of a leaf is stamped with the leaf's path code (FaceRec::code).
+// `path`: the nodes below the root on the way to this one; every leaf appends its path to `leaf_paths`
+// (one vector per leaf, in visiting order) and stamps its faces with its ordinal there.
 static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp, int first, int n, int leaf_max,
-                           int level, uint32_t code, int *ref_depth) {
+                           int level, uint32_t code, int *ref_depth, std::vector<int> &path,
+                           std::vector<std::vector<int>> &leaf_paths) {
   if (level > *ref_depth) *ref_depth = level;
   BvhNode nd;
   for (int k = 0; k < 3; k++) nd.mn[k] = INFINITY, nd.mx[k] = -INFINITY;
@@ -389,24 +393,28 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
     }
   int me = (int)nodes.size();
   nodes.push_back(nd);
+  if (level > 0) path.push_back(me);
   if (n <= leaf_max) {
     nodes[me].left = -1;
     nodes[me].right = -n;
-    for (int i = 0; i < n; i++) fp[first + i].code = code;
-    return me;
+    for (int i = 0; i < n; i++) fp[first + i].code = code, fp[first + i].leaf = (int)leaf_paths.size();
+    leaf_paths.push_back(path);
+  } else {
+    int mid = (n - 1) / 2;
+    const uint32_t bit = level < 32 ? 0x80000000u >> level : 0u;
+    int l = build_bvh_nodes(nodes, fp, first, mid + 1, leaf_max, level + 1, code, ref_depth, path, leaf_paths);
+    int r = build_bvh_nodes(nodes, fp, first + mid + 1, n - mid - 1, leaf_max, level + 1, code | bit, ref_depth, path,
+                            leaf_paths);
+    nodes[me].left = l;
+    nodes[me].right = r;
   }
-  int mid = (n - 1) / 2;
-  const uint32_t bit = level < 32 ? 0x80000000u >> level : 0u;
-  int l = build_bvh_nodes(nodes, fp, first, mid + 1, leaf_max, level + 1, code, ref_depth);
-  int r = build_bvh_nodes(nodes, fp, first + mid + 1, n - mid - 1, leaf_max, level + 1, code | bit, ref_depth);
-  nodes[me].left = l;
-  nodes[me].right = r;
+  if (level > 0) path.pop_back();
   return me;
 }
 
 std::string Scene::flatten() {
   pair_boxes.clear(), pair_pts.clear(), list_mag = 0.f;
-  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(),
+  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
   n_pgrams = n_triangles = n_spheres = 0;
@@ -525,7 +533,9 @@ std::string Scene::flatten() {
         int depth = 0;
         // an empty mesh is a leaf that can never report a hit: it contributes nothing
         int ref_depth = 0;
-        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, fp, 0, hb.n, leaf_max, 0, 0u, &ref_depth) : -1;
+        std::vector<int> path_now;
+        std::vector<std::vector<int>> local_paths;
+        br.root = hb.n > 0 ? build_bvh_nodes(local_nodes, fp, 0, hb.n, leaf_max, 0, 0u, &ref_depth, path_now, local_paths) : -1;
         if (ref_depth > kRefDepthMax) return "mesh tree too deep for the kernel's leaf path codes";
         br.sub_root = hb.n > 0 ? build_subtree(local_sub, fp, 0, hb.n, &depth) + sub_base : -1;
         sub_depth = std::max(sub_depth, depth);
@@ -549,6 +559,21 @@ std::string Scene::flatten() {
           qnodes.push_back(nd);
         }
         if (br.root >= 0) br.root += node_base;
+        // the leaves' root-to-leaf paths as a table: row = leaf ordinal; the leaf's path code, then ref_depth
+        // columns (the node at level 1, 2, ...), -1 below the leaf (kernels.hip, replay)
+        br.path_base = (int)leaf_paths.size();
+        if ((int64_t)leaf_paths.size() + (int64_t)local_paths.size() * (ref_depth + 1) > (int64_t)kLeafPathMax)
+          return "mesh leaf-path table too large";
+        {
+          std::vector<uint32_t> leaf_code(local_paths.size(), 0u);
+          for (int i = 0; i < hb.n; i++) leaf_code[(size_t)fp[i].leaf] = fp[i].code;
+          for (size_t li = 0; li < local_paths.size(); li++) {
+            const std::vector<int> &lp = local_paths[li];
+            leaf_paths.push_back((int32_t)leaf_code[li]);
+            for (int lvl = 0; lvl < ref_depth; lvl++)
+              leaf_paths.push_back(lvl < (int)lp.size() ? lp[(size_t)lvl] + node_base : -1);
+          }
+        }
         if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
         if (has_uv) face_uv.resize((size_t)(face_base + hb.n) * 6, 0.f);
         for (int i = 0; i < hb.n; i++) {  // physical order = search-tree order
@@ -557,6 +582,7 @@ std::string Scene::flatten() {
           for (int c = 0; c < 3; c++) f.p0[c] = t.p0[c], f.e1[c] = t.e1[c], f.e2[c] = t.e2[c];
           f.orig = fp[i].orig;
           f.code = fp[i].code;
+          f.leaf = fp[i].leaf;
           faces.push_back(f);
           if (has_uv)  // texture coordinates stay in the reference's order, addressed by `orig`
             for (int j = 0; j < 6; j++) face_uv[(size_t)(face_base + fp[i].orig) * 6 + j] = fp[i].uv[j];

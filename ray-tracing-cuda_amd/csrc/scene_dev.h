@@ -134,6 +134,8 @@ constexpr int kMeshStackWords = 512;  // node entries grow up from 0, face-block
 constexpr int kMeshWaveWords = 64 * kMeshRayWords + kMeshStackWords;
 constexpr uint32_t kCodeNone = 0xffffffffu;  // "no cut": no leaf code has bit 0 set (kRefDepthMax = 31)
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
+constexpr int kLeafPathMax = 1 << 26;  // words of SceneDev::leaf_paths (leaves x deepest path, summed over the meshes)
+constexpr int kLdsPaths = 1024;        // ... of which this many are staged in LDS (4 KiB)
 constexpr int kRefDepthMax = 31;  // decisions below the root that a leaf's path code can hold
 constexpr int kMeshMaxFaces = 1 << 23;   // a stack entry is 6 bits of ray + 26 bits of (first face * 8 + count) ...
 constexpr int kMeshMaxNodes = 1 << 26;   // ... or of node index
@@ -146,7 +148,7 @@ struct BvhRec {  // one per BVH hitable
   int32_t sub_root;   // root of the mesh's 4-wide search tree
   float mag;          // largest |coordinate| of the mesh's bounds (scales the search's distance slack)
   int32_t ref_depth;  // decisions on the longest root-to-leaf path of the reference tree (0: the root is a leaf)
-  int32_t pad;
+  int32_t path_base;  // first word of this mesh's rows in SceneDev::leaf_paths
 };
 
 struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the winner only
@@ -157,7 +159,7 @@ struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the win
   uint32_t code;  // the reference leaf holding the face: its left(0)/right(1) decisions below the
                   // root, first decision in bit 31, zero-filled.  Leaves are never prefixes of each
                   // other, so codes identify leaves and increase in the reference's visiting order.
-  int32_t pad;
+  int32_t leaf;   // ordinal of that leaf in visiting order: its row in the mesh's leaf-path table
 };
 
 struct CameraDev {
@@ -178,6 +180,9 @@ struct SceneDev {
   const BvhRec *bvhs;
   const BvhNode *nodes;
   const QNode4 *qnodes;
+  const int32_t *leaf_paths;  // per mesh (BvhRec::path_base): one row of ref_depth node indices per reference leaf,
+                              // the nodes below the root on the way to the leaf, -1 past it
+  int32_t n_leaf_paths;       // words in leaf_paths
   const FaceRec *faces;
   const float *face_uv;  // 6 floats per face or nullptr
   const MatRec *mats;

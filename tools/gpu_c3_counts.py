@@ -15,3 +15,10 @@ t = c.reshape(128, 8, 128, 8).sum(axis=(1, 3))
 print("tile max", t.max(), "tile p99", np.percentile(t, 99), "tile median", np.median(t), "tiles >= 2x mean", (t >= 2 * t.mean()).sum(), "of", t.size)
 for thr in (1000, 2000, 3000, 4000, 5000):
     print("pixels with >=", thr, "rays:", (c >= thr).sum())
+if len(sys.argv) > 2:  # dump the full-spp counts and the 2-spp probe counts for offline scheduling studies
+    out = sys.argv[2]
+    np.save(os.path.join(out, "c3_counts.npy"), c.astype(np.int32))
+    P = rtmi.Renderer(b, 1024, 1024, 2, 10).init_rng()
+    P.render(); torch.cuda.synchronize()
+    _, pc = P.untile()
+    np.save(os.path.join(out, "c3_probe.npy"), pc.cpu().numpy().astype(np.int32))

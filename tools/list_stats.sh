@@ -13,5 +13,12 @@ R.render(); torch.cuda.synchronize()
 out = (C.c_ulonglong * 32)()
 rtmi.lib().rtmi_debug_counters(b.h, out, None)
 rays, wq, bits, iters, crays = out[1], out[4], out[30], out[31], out[3]
+life = out[26]
+names = ["gen", "list", "search", "replay", "shade", "cull", "tasks+tests+fold", "fold"]
+for i, n in enumerate(names):
+    if out[17 + i]:
+        print("  %-18s %5.1f%% of wave time, %7.0f cycles per wave_query" % (n, 100.0 * out[17 + i] / life, out[17 + i] / max(wq, 1)))
+print("  shade: up to the material record (divergent lanes stamp separately: upper bound) %.0f, up to before the fold %.0f cycles per wave_query" % (out[25] / max(wq, 1), out[6] / max(wq, 1)))
+print("  wave life mean %.1f Mcyc max %.1f Mcyc, %d waves; cycles per wave_query %.0f" % (life / max(out[28], 1) / 1e6, out[27] / 1e6, out[28], life / max(wq, 1)))
 print("rays %d wave_queries %d: candidate pairs per ray %.2f (of %d lane-chunks), wave iterations per query %.2f" % (rays, wq, bits / max(crays, 1), crays, iters / max(wq, 1)))
 PY

@@ -44,6 +44,13 @@ if hasattr(L, "rtmi_debug_wave_stats"):
     setup = (ws[:, 15] >> np.uint64(32)).astype(np.float64); ctrl = (ws[:, 15] & np.uint64(0xffffffff)).astype(np.float64) * 256
     ws = ws.astype(np.float64)
     order = np.argsort(-ws[:, 0])
+    lifes = np.sort(ws[:, 0])
+    print("wave life percentiles (Mcyc): " + "  ".join("p%d %.0f" % (q, np.percentile(lifes, q) / 1e6) for q in (1, 10, 25, 50, 75, 90, 99, 100)))
+    for lo, hi in ((0, 10), (10, 25), (25, 50), (50, 75), (75, 90), (90, 100)):
+        a, b2 = np.percentile(lifes, lo), np.percentile(lifes, hi)
+        sel = ws[(ws[:, 0] >= a) & (ws[:, 0] <= b2)]
+        print("  life p%d..p%d: %d waves, mean queries %.0f, cycles/query %.0f, nodes/query %.0f"
+              % (lo, hi, len(sel), sel[:, 10].mean(), (sel[:, 0] / np.maximum(sel[:, 10], 1)).mean(), (sel[:, 13] / np.maximum(sel[:, 10], 1)).mean()))
     cols = ["life", "gen", "list", "search", "replay", "shade", "nfetch", "ntest", "npush", "face", "queries", "nsteps", "fsteps", "npopped", "ins"]
     print("top waves by life (Mcyc; then per query cycles):")
     for w in order[:6].tolist() + order[len(order) // 2: len(order) // 2 + 2].tolist():
