@@ -371,6 +371,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
   if ((rc = upload(s, s->qnodes, &d.qnodes))) return rc;
   if ((rc = upload(s, s->leaf_paths, &d.leaf_paths))) return rc;
+  if ((rc = upload(s, s->tops, &d.tops))) return rc;
   if ((rc = upload(s, s->faces, &d.faces))) return rc;
   if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;

@@ -479,13 +479,18 @@ struct MeshStats {
   unsigned long long cyc[11];  // [9] search setup before the first step, [10] between steps (loop control)
 };
 __device__ unsigned long long g_wave_stats[16384][16];  // per wave: life, cyc[0..8], wave_queries, node_steps, face_steps
-__device__ __forceinline__ unsigned long long stat_now() {
+__device__ __forceinline__ unsigned long long stat_real() {
   __builtin_amdgcn_sched_barrier(0);
   unsigned long long t;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   __builtin_amdgcn_sched_barrier(0);
   return t;
 }
+#if RTMI_STATS == 9  // counts and wave lifetimes only: no stamps inside the loop, timing as in the product build
+__device__ __forceinline__ unsigned long long stat_now() { return 0ull; }
+#else
+__device__ __forceinline__ unsigned long long stat_now() { return stat_real(); }
+#endif
 #define RTMI_STAT(x) x
 #if RTMI_STATS == 2
 #define RTMI_STAT2(x) x  // per-step stamps (a stamp costs several hundred cycles: they distort what they measure)
@@ -506,8 +511,9 @@ __device__ __forceinline__ unsigned long long stat_now() {
 // One search pass for the lanes with `need`: afterwards every such lane's record holds, per
 // reference leaf with lo_code <= code < cut, the best face with t_from <= t <= bt_to.
 template <typename T, bool DT>
-__device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, float mag, int *wl, bool need, V3 o, V3 d,
-                                            V3 inv_d, T bt_to, uint32_t lo_code, unsigned long long *overflow
+__device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, const BvhNode *top, float mag, int *wl,
+                                            bool need, V3 o, V3 d, V3 inv_d, T bt_to, uint32_t lo_code,
+                                            unsigned long long *overflow
 #ifdef RTMI_STATS
                                             , MeshStats &st
 #endif
@@ -532,9 +538,43 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
     *reinterpret_cast<int4 *>(rr + 12) = make_int4(0, (int)kCodeNone, (int)lo_code, 0);
   }
   const unsigned long long nm = __ballot(need);
-  if (need) stack[lane_rank(nm)] = (lane << 26) | sub_root;
-  int sn = __popcll(nm), sf = 0;
   const int reserve = sc.sub_reserve;
+  int sn = 0, sf = 0;
+  if (__popcll(nm) <= kTopRays) {
+    // Few rays (the tail of a frame, or a wave that holds outlier pixels): the levels below the root,
+    // where a step has next to nothing to do, are skipped.  Lane l holds sub-tree l of the mesh's top
+    // table; one ray at a time is tested against all of them at once and the sub-trees it touches go
+    // onto the stack.  (Boxes as conservative as the node boxes they stand for: scene.hip.)
+    const BvhNode te = top[lane];
+    const float far = (float)bt_to * 1.0001f + 1e-6f;
+    for (unsigned long long m = nm; m != 0ull; m &= m - 1ull) {
+      const int rl = __builtin_ctzll(m);  // wave-uniform
+      if (kMeshStackWords - sn - sf - reserve < kTopEntries) {  // no room for a whole table: start this ray at the root
+        if (lane == 0) stack[sn] = (rl << 26) | sub_root;
+        sn++;
+        continue;
+      }
+      const V3 ro = mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.x), rl)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.y), rl)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(o.z), rl)));
+      const V3 ri = mk(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_d.x), rl)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_d.y), rl)),
+                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_d.z), rl)));
+      const float rfar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(far), rl));
+      const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)) + mag);
+      const bool hit = te.left != -1 && slab_touch(te, delta, ro, ri, lo0, rfar);
+      const bool pn = hit && te.left >= 0, pf = hit && te.left < 0;
+      const unsigned long long mn_ = __builtin_amdgcn_ballot_w64(pn), mf_ = __builtin_amdgcn_ballot_w64(pf);
+      const uint32_t owner_bits = (uint32_t)rl << 26;
+      if (pn) stack[sn + lane_rank(mn_)] = (int)(owner_bits | (uint32_t)te.left);
+      if (pf) stack[kMeshStackWords - 1 - sf - lane_rank(mf_)] = (int)(owner_bits | (uint32_t)(-(te.left + 1)));
+      sn += __popcll(mn_);
+      sf += __popcll(mf_);
+    }
+  } else {
+    if (need) stack[lane_rank(nm)] = (lane << 26) | sub_root;
+    sn = __popcll(nm);
+  }
   wave_lds_fence();
   RTMI_STAT(unsigned long long tprev = stat_now(); st.cyc[9] += tprev - tset0;
             { const unsigned long long cb = stat_now(); st.calib += cb - tprev; tprev = cb; } (void)tprev;)
@@ -544,12 +584,13 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
       // Few blocks pending (the tail of a search, or a wave with one deep ray among 64): four lanes
       // per block, one face each -- one memory round trip and one triangle test deep.  Otherwise one
       // lane per block of up to four faces.
-      const bool wide = sf <= 16;
+      const bool wide = sf <= 16, pair = !wide && sf <= 32;  // four / two lanes per block, or one
       const int kf = sf < 64 ? sf : 64;
       RTMI_STAT(st.face_steps++; st.blocks_popped += kf; my_steps++;)
       RTMI_STAT2(const unsigned long long tf0 = stat_now(); st.cyc[10] += tf0 - tprev;)
-      const int slot = wide ? (lane >> 2) : lane;
+      const int slot = wide ? (lane >> 2) : pair ? (lane >> 1) : lane;
       const bool mine = slot < kf;
+      const int fstride = pair ? 2 : 1;  // result bit j stands for face first + j * fstride
       int e = 0;
       if (mine) e = stack[kMeshStackWords - sf + slot];
       sf -= kf;
@@ -580,6 +621,39 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
           th = th && t < -1.f;  // never
 #endif
           if (th) pend = 1u, pt0 = t, po0 = c.y, pc0 = c.w;
+        }
+      } else if (pair) {
+        first += lane & 1;  // this lane's faces: first, first + 2
+        if (mine) {
+          const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r1 = *reinterpret_cast<const float4 *>(rr + 4);
+          T t_to;
+          if (DT) {
+            t_to = (T)__hiloint2double(__float_as_int(r1.w), __float_as_int(r0.w));
+          } else {
+            t_to = (T)r0.w;
+          }
+          const V3 ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
+          const float4 *fp4 = reinterpret_cast<const float4 *>(sc.faces + first);
+          const int left = fcnt - (lane & 1);  // faces first + 2 * fi exist for 2 * fi < left
+          float4 q[6];
+#pragma unroll
+          for (int w = 0; w < 3; w++) q[w] = fp4[w], q[3 + w] = fp4[6 + w];  // `faces` carries 4 records of padding
+#pragma unroll
+          for (int fi = 0; fi < 2; fi++) {
+            if (2 * fi < left) {
+              const float4 a = q[fi * 3], b = q[fi * 3 + 1], c = q[fi * 3 + 2];
+              float t = 0.f, u = 0.f, v = 0.f;
+              bool th = tri_test<T>(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), ro, rd, t_to, t, u, v);
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 2
+              th = th && t < -1.f;  // never
+#endif
+              if (th) {
+                pend |= 1u << fi;
+                if (fi == 0) pt0 = t, po0 = c.y, pc0 = c.w;
+                if (fi == 1) pt1 = t, po1 = c.y, pc1 = c.w;
+              }
+            }
+          }
         }
       } else if (mine) {
         const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r1 = *reinterpret_cast<const float4 *>(rr + 4);
@@ -629,7 +703,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
           const float t = j == 0 ? pt0 : j == 1 ? pt1 : j == 2 ? pt2 : pt3;
           const float fo = j == 0 ? po0 : j == 1 ? po1 : j == 2 ? po2 : po3;
           const float fc = j == 0 ? pc0 : j == 1 ? pc1 : j == 2 ? pc2 : pc3;
-          hit_list_insert(sc, rr, (uint32_t)__float_as_int(fc), first + j, __float_as_int(fo), t);
+          hit_list_insert(sc, rr, (uint32_t)__float_as_int(fc), first + j * fstride, __float_as_int(fo), t);
           pend &= pend - 1u;
         }
         wave_lds_fence();
@@ -637,10 +711,12 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
       RTMI_STAT2(tprev = stat_now(); st.cyc[8] += tprev - tf0;)
     } else {
       // ---------------------------------------------------------------- node step
-      const bool wide = sn <= 16;  // four lanes per entry, one child box each (see the face step)
+      // four lanes per entry with one child box each, two with two, or one with all four (see the face step)
+      const bool wide = sn <= 16, pair = !wide && sn <= 32;
+      const int kmax = wide ? 16 : pair ? 32 : 64;
       int k = (kMeshStackWords - sn - sf - reserve) / 3;
       k = k < 1 ? 1 : k;
-      k = k > (wide ? 16 : 64) ? (wide ? 16 : 64) : k;
+      k = k > kmax ? kmax : k;
       k = k > sn ? sn : k;
       if (3 * k > kMeshStackWords - sn - sf) {  // cannot happen (see above); never write out of range
         if (lane == 0) atomicAdd(overflow, 1ull);
@@ -648,7 +724,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
       }
       RTMI_STAT(st.node_steps++; st.nodes_popped += k; my_steps++;)
       RTMI_STAT2(const unsigned long long tn0 = stat_now(); unsigned long long tn1 = tn0; st.cyc[10] += tn0 - tprev;)
-      const int slot = wide ? (lane >> 2) : lane;
+      const int slot = wide ? (lane >> 2) : pair ? (lane >> 1) : lane;
       const bool mine = slot < k;
       int e = 0;
       if (mine) e = stack[sn - 1 - slot];
@@ -658,7 +734,40 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
       const int owner = (int)((unsigned)e >> 26), idx = e & (kMeshMaxNodes - 1);
       const uint4 *np = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
       const int *rr = wl + owner * kMeshRayWords;
-      if (wide) {
+      // children that were touched: nodes onto the node end, face blocks onto the face end
+#define RTMI_PUSH_CHILD(H, C)                                                           \
+  {                                                                                     \
+    const bool pn = (H) && (C) >= 0, pf = (H) && (C) < 0;                               \
+    const unsigned long long mn_ = __builtin_amdgcn_ballot_w64(pn), mf_ = __builtin_amdgcn_ballot_w64(pf); \
+    if (pn) stack[sn + lane_rank(mn_)] = (int)(owner_bits | (uint32_t)(C));             \
+    if (pf) stack[kMeshStackWords - 1 - sf - lane_rank(mf_)] = (int)(owner_bits | (uint32_t)(-((C) + 1))); \
+    sn += __popcll(mn_);                                                                \
+    sf += __popcll(mf_);                                                                \
+  }
+      if (pair) {
+        bool ha = false, hb = false;
+        int ca = -1, cb = -1;
+        if (mine) {
+          const int c = lane & 1;  // this lane's children: c, c + 2
+          const uint4 w0 = np[0], w1 = np[1];
+          const uint2 w2 = *reinterpret_cast<const uint2 *>(np + 2);
+          ca = reinterpret_cast<const int *>(np + 3)[c], cb = reinterpret_cast<const int *>(np + 3)[c + 2];
+          const float4 r0 = *reinterpret_cast<const float4 *>(rr + 0), r2 = *reinterpret_cast<const float4 *>(rr + 8);
+          NodeFrame nf;
+          node_frame(w0, r0, r2, mag, nf);
+          const int sa = 8 * c, sb = 8 * c + 16;
+          const bool ba = child_box_hit(nf, (float)((w1.x >> sa) & 0xffu), (float)((w1.y >> sa) & 0xffu),
+                                        (float)((w1.z >> sa) & 0xffu), (float)((w1.w >> sa) & 0xffu),
+                                        (float)((w2.x >> sa) & 0xffu), (float)((w2.y >> sa) & 0xffu), lo0, r2.w);
+          const bool bb = child_box_hit(nf, (float)((w1.x >> sb) & 0xffu), (float)((w1.y >> sb) & 0xffu),
+                                        (float)((w1.z >> sb) & 0xffu), (float)((w1.w >> sb) & 0xffu),
+                                        (float)((w2.x >> sb) & 0xffu), (float)((w2.y >> sb) & 0xffu), lo0, r2.w);
+          ha = (ca != -1) & ba, hb = (cb != -1) & bb;
+        }
+        RTMI_PUSH_CHILD(ha, ca)
+        RTMI_PUSH_CHILD(hb, cb)
+        wave_lds_fence();
+      } else if (wide) {
         bool hit = false;
         int child = -1;
         if (mine) {
@@ -706,16 +815,6 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, fl
           c0 = cch[0], c1 = cch[1], c2 = cch[2], c3 = cch[3];
         }
         RTMI_STAT2(const unsigned long long tn2 = stat_now(); st.cyc[5] += tn1 - tn0; st.cyc[6] += tn2 - tn1;)
-        // children that were touched: nodes onto the node end, face blocks onto the face end
-#define RTMI_PUSH_CHILD(H, C)                                                           \
-  {                                                                                     \
-    const bool pn = (H) && (C) >= 0, pf = (H) && (C) < 0;                               \
-    const unsigned long long mn_ = __builtin_amdgcn_ballot_w64(pn), mf_ = __builtin_amdgcn_ballot_w64(pf); \
-    if (pn) stack[sn + lane_rank(mn_)] = (int)(owner_bits | (uint32_t)(C));             \
-    if (pf) stack[kMeshStackWords - 1 - sf - lane_rank(mf_)] = (int)(owner_bits | (uint32_t)(-((C) + 1))); \
-    sn += __popcll(mn_);                                                                \
-    sf += __popcll(mf_);                                                                \
-  }
         RTMI_PUSH_CHILD(h0, c0)
         RTMI_PUSH_CHILD(h1, c1)
         RTMI_PUSH_CHILD(h2, c2)
@@ -1078,7 +1177,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         while (__ballot(need) != 0ull) {
           // ---- (1) search: best face per leaf with lo_code <= code < cut, t <= bt_to
           RTMI_STAT(const unsigned long long ts0 = stat_now();)
-          mesh_search<T, DT>(sc, br.sub_root, br.mag, wl, need, o, d, inv_d, bt_to, lo_code, overflow
+          mesh_search<T, DT>(sc, br.sub_root, sc.tops + (size_t)(run.first + i) * kTopEntries, br.mag, wl, need, o, d, inv_d,
+                             bt_to, lo_code, overflow
 #ifdef RTMI_STATS
                              , st
 #endif
@@ -1398,7 +1498,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     return true;
   };
 
-  RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_now();)
+  RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();)
   for (;;) {
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
     // -------------------------------------------------------- sample / pixel bookkeeping
@@ -1685,7 +1785,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                             st.steps_hist[4], st.steps_hist[5]};
     for (int i = 0; i < 13; i++) atomicAdd(&counters[4 + i], (unsigned long long)v[i]);
     for (int i = 0; i < 9; i++) atomicAdd(&counters[17 + i], st.cyc[i]);
-    const unsigned long long life = stat_now() - t_begin;
+    const unsigned long long life = stat_real() - t_begin;
     atomicAdd(&counters[26], life);
     atomicMax(&counters[27], life);
     atomicAdd(&counters[28], 1ull);

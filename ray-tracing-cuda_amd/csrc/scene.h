@@ -68,6 +68,7 @@ struct Scene {
   std::vector<BvhRec> bvh_recs;
   std::vector<BvhNode> nodes;
   std::vector<QNode4> qnodes;
+  std::vector<BvhNode> tops;        // per BVH record: kTopEntries sub-trees of its search tree (box, child reference)
   std::vector<int32_t> leaf_paths;  // per mesh: rows of ref_depth reference-node indices, one row per reference leaf
   int sub_depth = 0;  // deepest search tree (levels of QNode4)
   std::vector<FaceRec> faces;

@@ -368,6 +368,59 @@ static int build_subtree(std::vector<QNode4> &qn, std::vector<FacePts> &fp, int 
   return collapse4(qn, bn, root, depth);
 }
 
+// The top of a mesh's search tree as a flat table of kTopEntries sub-trees (kernels.hip, mesh_search:
+// a wave with few rays tests all of them at once instead of descending level by level).  Starting
+// from the root's children, the sub-tree with the largest surface is replaced by its children while
+// the table has room.  Boxes: the children's quantised boxes, rounded outward to binary32.
+static void build_top_entries(const std::vector<QNode4> &qn, int sub_root, std::vector<BvhNode> &tops) {
+  struct Entry {
+    float mn[3], mx[3];
+    int ref;
+  };
+  std::vector<Entry> fr;
+  auto expand = [&](int node) {
+    const QNode4 &nd = qn[(size_t)node];
+    for (int c = 0; c < 4; c++) {
+      if (nd.child[c] == -1) continue;
+      Entry e;
+      for (int a = 0; a < 3; a++) {
+        const double lo = (double)nd.origin[a] + std::ldexp((double)nd.qlo[a][c], nd.exp[a]);
+        const double hi = (double)nd.origin[a] + std::ldexp((double)nd.qhi[a][c], nd.exp[a]);
+        e.mn[a] = nextafterf(nextafterf((float)lo, -INFINITY), -INFINITY);
+        e.mx[a] = nextafterf(nextafterf((float)hi, INFINITY), INFINITY);
+      }
+      e.ref = nd.child[c];
+      fr.push_back(e);
+    }
+  };
+  if (sub_root >= 0) expand(sub_root);
+  for (;;) {
+    int best = -1;
+    double ba = -1.0;
+    for (size_t i = 0; i < fr.size(); i++)
+      if (fr[i].ref >= 0) {
+        const double ar = half_area(fr[i].mn, fr[i].mx);
+        if (ar > ba) ba = ar, best = (int)i;
+      }
+    if (best < 0 || fr.size() + 3 > (size_t)kTopEntries) break;
+    const int node = fr[(size_t)best].ref;
+    fr.erase(fr.begin() + best);
+    expand(node);
+  }
+  for (int i = 0; i < kTopEntries; i++) {
+    BvhNode t;
+    if (i < (int)fr.size()) {
+      for (int a = 0; a < 3; a++) t.mn[a] = fr[(size_t)i].mn[a], t.mx[a] = fr[(size_t)i].mx[a];
+      t.left = fr[(size_t)i].ref;
+    } else {
+      for (int a = 0; a < 3; a++) t.mn[a] = 1.f, t.mx[a] = -1.f;
+      t.left = -1;  // unused slot
+    }
+    t.right = 0;
+    tops.push_back(t);
+  }
+}
+
 // bvh.cuh:113-121: bounds; leaf if n <= kMin; else sort by positions_[0].x and
 // split at mid = (n-1)/2.  The sort key never changes down the tree, so the
 // reference's per-node re-sort of an already sorted sub-range is the identity for
@@ -414,7 +467,7 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
 
 std::string Scene::flatten() {
   pair_boxes.clear(), pair_pts.clear(), list_mag = 0.f;
-  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(),
+  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(), tops.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
   n_pgrams = n_triangles = n_spheres = 0;
@@ -596,6 +649,7 @@ std::string Scene::flatten() {
         br.has_uv = has_uv ? 1 : 0;
         br.face_base = face_base;
         if (br.root >= 0) {
+          build_top_entries(qnodes, br.sub_root, tops);  // row = index of the record
           bvh_recs.push_back(br);
           push_run(RUN_BVH, (int)bvh_recs.size() - 1);
           features |= F_BVH;

@@ -134,6 +134,8 @@ constexpr int kMeshStackWords = 512;  // node entries grow up from 0, face-block
 constexpr int kMeshWaveWords = 64 * kMeshRayWords + kMeshStackWords;
 constexpr uint32_t kCodeNone = 0xffffffffu;  // "no cut": no leaf code has bit 0 set (kRefDepthMax = 31)
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
+constexpr int kTopEntries = 64;   // entries of a mesh's top table: one per lane
+constexpr int kTopRays = 16;      // a search that starts with at most this many rays starts from the top table
 constexpr int kLeafPathMax = 1 << 26;  // words of SceneDev::leaf_paths (leaves x deepest path, summed over the meshes)
 constexpr int kLdsPaths = 1024;        // ... of which this many are staged in LDS (4 KiB)
 constexpr int kRefDepthMax = 31;  // decisions below the root that a leaf's path code can hold
@@ -180,6 +182,7 @@ struct SceneDev {
   const BvhRec *bvhs;
   const BvhNode *nodes;
   const QNode4 *qnodes;
+  const BvhNode *tops;        // per BVH record: kTopEntries sub-trees of its search tree (mn, mx, left = child reference)
   const int32_t *leaf_paths;  // per mesh (BvhRec::path_base): one row of ref_depth node indices per reference leaf,
                               // the nodes below the root on the way to the leaf, -1 past it
   int32_t n_leaf_paths;       // words in leaf_paths
