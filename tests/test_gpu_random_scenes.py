@@ -270,3 +270,46 @@ def test_nested_lists_match_the_nested_oracle(seed):
     assert R.total_rays() == o_total
     assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
     assert np.array_equal(img.cpu().numpy(), o_rgb)
+
+
+def _clump(n, rng, spread):
+    """n faces around one point: centroids nearly coincide, so the search tree's splits fall back
+    to medians and the tree is as deep as it gets for n faces."""
+    c = rng.uniform(-0.2, 0.2, (n, 1, 3)) * spread + np.array([0.0, 0.3, -2.0])
+    return (c + rng.uniform(-0.5, 0.5, (n, 3, 3))).astype(np.float32)
+
+
+@pytest.mark.parametrize("case", [
+    # (frame h, w, spp, depth, faces per mesh, reference leaf size, meshes): frames of at most 16 pixels keep every
+    # search at <= 16 rays, i.e. on the top-table start; 5 x 13 starts dense and thins out towards the end of the frame
+    (3, 5, 9, 12, 600, 2, 1), (4, 4, 7, 20, 1, 2048, 3), (2, 8, 6, 12, 2500, 1, 2), (2, 2, 40, 30, 300, 4, 2),
+    (5, 13, 5, 12, 900, 3, 2), (3, 5, 9, 12, 70, 2048, 1),
+])
+def test_sparse_waves_start_from_the_top_table(case):
+    """Waves with a handful of rays (tiny frames) on deep, clumped meshes with small reference leaves:
+    the search starts from the mesh's table of sub-trees, runs in its four- and two-lanes-per-entry
+    modes, and the replay reads leaf-path rows of 8, 16 and 32 words, from LDS and from global memory."""
+    import torch
+    h, w, spp, depth, n_faces, k_min, n_meshes = case
+    results = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        rng = np.random.default_rng(977)
+        b = make(31)
+        b.camera_pinhole(v3(0.1, 0.4, 1.2), v3(0, 0.3, -2.0), v3(0, 1, 0), PI_D / 5, w / h)
+        mats = [b.dielectric(v3(0.95, 0.97, 0.99), 1.2), b.metal(v3(0.9, 0.85, 0.8), 0.2), b.lambertian(v3(0.8, 0.7, 0.6))]
+        for i in range(n_meshes):
+            b.bvh(_clump(n_faces, rng, 0.05 if i == 0 else 1.0), mats[i % 3], k_min=k_min)
+        b.parallelogram([v3(-50, -0.7, -50), v3(50, -0.7, -50), v3(-50, -0.7, 50)], b.lambertian(v3(0.5, 0.5, 0.5)))
+        b.sky()
+        results.append(b)
+    o, p = results
+    o_rgb, o_rays, o_states, o_total = o.render(h, w, spp, depth, post=False)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth, False).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert o_total > h * w * spp  # the meshes are in view
+    assert R.total_rays() == o_total
+    assert np.array_equal(cnt.cpu().numpy().astype(np.uint32), o_rays)
+    assert np.array_equal(img.cpu().numpy(), o_rgb), np.abs(img.cpu().numpy() - o_rgb).max()
