@@ -1377,10 +1377,12 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
 // ================================================================== trace kernel
 // Dynamic LDS: [ material records: lds_mats * 32 B ][ id stack: max_depth * blockDim entries ]
 // The id stack is laid out [depth][thread] so the lanes of a wave touch consecutive
-// bytes; entries are uint8 when every material id fits, else uint16 (lc.wide_ids).
+// bytes; entries are 4 bits when there are at most 16 materials (two levels per byte, lc.wide_ids == 2:
+// half the LDS, which is what lets a sixth wave per SIMD of the list kernel in at depth 50), uint8 when
+// every material id fits a byte, else uint16 (lc.wide_ids == 1).
 struct LaunchCfg {
   int32_t lds_mats;    // materials staged in LDS (0: read them from global memory)
-  int32_t wide_ids;    // 1: uint16 stack entries
+  int32_t wide_ids;    // 0: uint8 stack entries, 1: uint16, 2: 4-bit (two levels per byte)
   int32_t stack_off;   // byte offset of the id stack inside dynamic LDS
   int32_t nodes_off;   // byte offset of the staged reference-tree nodes
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
@@ -1405,8 +1407,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
   // id stack: byte offset of entry [level][thread] in LDS, kept as 32-bit arithmetic (pointer
   // arithmetic on the generic pointers costs a register pair per live address)
-  const uint32_t ids_shift = lc.wide_ids ? 1u : 0u;
-  auto ids_offset = [&](int level) -> uint32_t {
+  const uint32_t ids_shift = lc.wide_ids == 1 ? 1u : 0u;
+  const bool nibble_ids = lc.wide_ids == 2;
+  auto ids_offset = [&](int level) -> uint32_t {  // (nibble_ids: the byte of levels 2k and 2k + 1 is row k)
     return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << ids_shift);
   };
   const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
@@ -1426,7 +1429,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     ll = reinterpret_cast<int *>(smem + lc.list_off) +
          __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * 8 + kListTasks * (1 + ((F & F_TEX) ? 6 : 2)));
   const bool mats_in_lds = lc.lds_mats > 0;
-  const bool fast_fold = mats_in_lds && !lc.wide_ids && sc.unsigned_colours;  // see the radiance fold
+  const bool fast_fold = mats_in_lds && lc.wide_ids != 1 && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
     uint32_t *dst = reinterpret_cast<uint32_t *>(s_mats);
@@ -1711,6 +1714,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                 att[depth * 3 + 0] = rgb.x;
                 att[depth * 3 + 1] = rgb.y;
                 att[depth * 3 + 2] = rgb.z;
+              } else if (nibble_ids) {
+                const uint32_t at = ids_offset(depth >> 1);  // this lane's own byte: no other lane writes it
+                const uint32_t old = smem[at];
+                smem[at] = (uint8_t)((depth & 1) ? ((old & 0x0fu) | ((uint32_t)mat << 4)) : ((old & 0xf0u) | (uint32_t)mat));
               } else if (lc.wide_ids) {
                 *reinterpret_cast<uint16_t *>(smem + ids_offset(depth)) = (uint16_t)mat;
               } else {
@@ -1735,6 +1742,30 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           // common case (byte ids, material table in LDS, no signed colours) without the per-layer
           // uniform branches: four layers at a time, ids first, then colours, then the products
           const uint32_t step = blockDim.x;
+          if (nibble_ids) {
+            if (i >= 0 && !(i & 1)) {  // an even top level sits alone in the low half of its byte
+              const int m0 = smem[ids_offset(i >> 1)] & 15;
+              result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+              i--;
+            }
+            for (; i >= 3; i -= 4) {  // i odd: bytes (i >> 1) and (i >> 1) - 1 hold levels i, i - 1 and i - 2, i - 3
+              const uint32_t at = ids_offset(i >> 1);
+              const uint32_t b0 = smem[at], b1 = smem[at - step];
+              const int m0 = b0 >> 4, m1 = b0 & 15, m2 = b1 >> 4, m3 = b1 & 15;
+              const V3 a0 = mk(s_mats[m0].r, s_mats[m0].g, s_mats[m0].b), a1 = mk(s_mats[m1].r, s_mats[m1].g, s_mats[m1].b);
+              const V3 a2 = mk(s_mats[m2].r, s_mats[m2].g, s_mats[m2].b), a3 = mk(s_mats[m3].r, s_mats[m3].g, s_mats[m3].b);
+              result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
+              result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
+              result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
+              result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
+            }
+            for (; i >= 1; i -= 2) {
+              const uint32_t b0 = smem[ids_offset(i >> 1)];
+              const int m0 = b0 >> 4, m1 = b0 & 15;
+              result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+              result = mk(s_mats[m1].r * result.x, s_mats[m1].g * result.y, s_mats[m1].b * result.z);
+            }
+          }
           for (; i >= 3; i -= 4) {
             const uint32_t at = ids_offset(i);
             const int m0 = smem[at], m1 = smem[at - step], m2 = smem[at - 2u * step], m3 = smem[at - 3u * step];
@@ -1755,7 +1786,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           if (F & F_TEX) {
             a = mk(att[i * 3 + 0], att[i * 3 + 1], att[i * 3 + 2]);
           } else {
-            const int mi = lc.wide_ids ? (int)*reinterpret_cast<const uint16_t *>(smem + ids_offset(i)) : (int)smem[ids_offset(i)];
+            const int mi = nibble_ids     ? (int)((smem[ids_offset(i >> 1)] >> ((i & 1) * 4)) & 15u)
+                           : lc.wide_ids ? (int)*reinterpret_cast<const uint16_t *>(smem + ids_offset(i))
+                                         : (int)smem[ids_offset(i)];
             if (mats_in_lds) {
               a = mk(s_mats[mi].r, s_mats[mi].g, s_mats[mi].b);
             } else {
@@ -1814,7 +1847,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 // Second launch bound = waves per SIMD the register allocation must allow: the list-only variants
 // sit at the 80-VGPR / 6-wave step and are issue-bound (one wave less costs 5 %), so the step is
 // held explicitly instead of being left to the allocator's luck.
-#define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : ((F) & F_TRIS) ? 5 : 6)
+#ifndef RTMI_TRIS_WAVES
+#define RTMI_TRIS_WAVES 6
+#endif
+#define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
 // Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
 // workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
 #define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)
@@ -2000,10 +2036,11 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   LaunchCfg lc{};
   lc.tile_order = nullptr;
   lc.lds_mats = sc.n_mats <= kLdsMats ? sc.n_mats : 0;
-  lc.wide_ids = sc.n_mats > 256 ? 1 : 0;
+  lc.wide_ids = sc.n_mats > 256 ? 1 : sc.n_mats <= 16 ? 2 : 0;
   size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
   lc.stack_off = (int32_t)off;
-  size_t stack = (variant & F_TEX) ? 0 : (size_t)(fr.max_depth > 0 ? fr.max_depth : 1) * threads * (lc.wide_ids ? 2 : 1);
+  const size_t levels = (size_t)(fr.max_depth > 0 ? fr.max_depth : 1);
+  size_t stack = (variant & F_TEX) ? 0 : (lc.wide_ids == 2 ? (levels + 1) / 2 : levels) * threads * (lc.wide_ids == 1 ? 2 : 1);
   size_t noff = (off + stack + 15) & ~(size_t)15;
   lc.nodes_off = (int32_t)noff;
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;
