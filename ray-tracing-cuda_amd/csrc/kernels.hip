@@ -12,18 +12,21 @@
 //   * closest hit walks the world list in list order with wave-uniform control
 //     flow: every lane tests the same primitive, whose record arrives in SGPRs
 //     through scalar loads (s_load_dwordx8/x16, scalar cache) — no per-lane
-//     geometry traffic at all for list scenes;
+//     geometry traffic at all for list scenes; lists of four or more triangle pairs
+//     are culled first (each lane slab-tests every pair's padded bounds, the surviving
+//     (ray, pair) candidates of the whole wave are tested by all 64 lanes from LDS and
+//     folded per ray in list order);
 //   * acceptance bookkeeping in the loop is 3 VGPRs (ok, t_to, winner id); the
 //     winner's normal / material are resolved once per ray after the loop;
 //   * the material table is staged in LDS once per workgroup, and so is the per-lane
 //     stack of scattered-material ids that the back-to-front radiance fold of
-//     ray_tracing.cu:50-52 needs (one byte per bounce instead of a 12-byte
+//     ray_tracing.cu:50-52 needs (four bits or a byte per bounce instead of a 12-byte
 //     attenuation in scratch memory);
 //   * mesh (BVH) queries do not walk the reference's tree: one search of a mesh-wide
-//     4-wide tree finds the best face of every reference leaf that holds a hit, then the
-//     reference's box tests are replayed on those leaves' root-to-leaf paths only
-//     (closest_hit, RUN_BVH); the last few searches of a wave are finished by all 64
-//     lanes together (coop_finish);
+//     4-wide tree, done by the wave for all its rays at once (mesh_search), finds the best
+//     face of every reference leaf that holds a hit, then the reference's box tests are
+//     replayed on those leaves' root-to-leaf paths only, again one (leaf, level) per lane
+//     (closest_hit, RUN_BVH);
 //   * arithmetic follows the reference operation by operation (binary32 with
 //     the binary64 islands of sphere.cu / ray_tracing.cu:68-73); the file is
 //     compiled with -ffp-contract=off and IEEE divide/sqrt.  The one shortened
