@@ -1,0 +1,541 @@
+// HitableList::Hit over the flattened world: list scan (plain and culled), spheres, mesh search + replay.
+// Included by kernels.hip inside namespace rtmi, after mesh_search.h (not a stand-alone header).
+#pragma once
+
+// ================================================================== closest hit
+// HitableList::Hit (hitable_list.cu:7-25) over the flattened world.  A nested
+// Parallelepiped list is equivalent to its six parallelograms inlined at its
+// position (DESIGN.md "List flattening").
+// `live`: mesh variants are entered by ALL lanes of the wave (the mesh search borrows idle
+// lanes); a lane that is not tracing passes live = false and gets an unused result.  The other
+// variants are only entered by tracing lanes and pass true.
+template <uint32_t F>
+__device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, const int *s_paths,
+                                           int lds_paths, const float4 *s_pairs, int *ll, int *wl, unsigned long long *overflow, V3 o,
+                                           V3 d, bool live
+#ifdef RTMI_STATS
+                                           , MeshStats &st
+#endif
+) {
+  constexpr bool DT = (F & F_SPHERE) != 0;
+  typedef typename TSel<DT>::type T;
+  bool ok = false;
+  T t_to = (T)INFINITY;
+  uint32_t win = ID_NONE;
+  int32_t aux = 0;
+  float bu = 0.f, bv = 0.f;
+
+  double sa = 0.0, sa2 = 0.0;
+  float saf = 0.f;
+  if (F & F_SPHERE) {
+    float la = len3(d);       // sphere.cu:13: pow(length(dir), 2) in float, then widened
+    saf = la * la;
+    sa = (double)saf;
+    sa2 = 2 * sa;
+  }
+
+  const int lane = (int)(threadIdx.x & 63u);
+  // the ray as the culled list scan wants it: 1/d (the hardware reciprocal will do: the test is conservative by
+  // a margin of 1e-5, not 1e-7), and -(o +- delta)/d per axis, delta = the distance slack of the mesh search
+  V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
+  if ((F & F_TRIS) && s_pairs != nullptr) {
+    const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
+    cull_inv = mk(fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : ix, fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : iy,
+                  fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : iz);
+    const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.list_mag);
+    cull_klo = mk(-(o.x + delta) * cull_inv.x, -(o.y + delta) * cull_inv.y, -(o.z + delta) * cull_inv.z);  // lower planes, moved out
+    cull_khi = mk(-(o.x - delta) * cull_inv.x, -(o.y - delta) * cull_inv.y, -(o.z - delta) * cull_inv.z);  // upper planes
+  }
+
+  for (int ri = 0; ri < sc.n_runs; ri++) {
+    const i32x4 rv = load_run(sc.runs, ri);
+    Run run;
+    run.kind = rv[0], run.first = rv[1], run.count = rv[2], run.pad = 0;
+    if (live && run.kind == RUN_SKY) {
+      // sky.cu:18-27: t = 1e9; t_from <= 1e9 always holds
+      const T ts = (T)1e9f;
+      bool hit = ts <= t_to;
+      bool acc = hit && (!ok || ts < t_to);
+      ok = ok || acc;
+      t_to = acc ? ts : t_to;
+      win = acc ? make_id(RUN_SKY, 0) : win;
+    }
+    if ((F & F_TRIS) && run.kind == RUN_TRIS && s_pairs != nullptr) {
+      // Culled scan (DESIGN.md "World-list scan").  The reference tests every entry of the list against
+      // every ray (hitable_list.cu:11-22); what it RETURNS only depends on the entries whose test can
+      // succeed, visited in list order.  Lanes of a wave carry unrelated rays, so no entry can be
+      // skipped for the whole wave -- but each lane can skip its own: (1) every pair's padded bounds
+      // (one s_load_dwordx8, wave-uniform) against the lane's ray: a slab test, 27 instructions
+      // instead of the 140 of two triangle tests, builds a bit mask of the pairs this ray comes near;
+      // (2) while any lane has bits left, each lane takes ITS next pair -- a different one per lane,
+      // corners gathered from LDS -- and runs the reference's two triangle tests on it.  A lane visits
+      // its pairs in list order with its own running t_to, so acceptance and ties are as in the full
+      // scan; a pair outside the mask cannot pass the triangle test (the bounds carry the same padding
+      // and distance slack as the mesh search boxes).
+      const int pair0 = run.first >> 1;
+      const float lo0 = T_FROM_F * 0.999f;
+      for (int c0 = 0; c0 < run.count; c0 += 32) {
+        const int nc = run.count - c0 < 32 ? run.count - c0 : 32;
+        const float hi0 = (float)t_to * 1.0001f + 1e-6f;
+        uint32_t mask = 0u;
+        RTMI_STAT2(const unsigned long long tc0 = stat_now();)
+        f32x8 nxt = load_pair_box(sc.pair_boxes, pair0 + c0);
+        for (int i = 0; i < nc; i++) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the plain scan below
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x8 bx = nxt;
+          nxt = load_pair_box(sc.pair_boxes, pair0 + c0 + i + 1);  // (one inert record of padding at the end)
+          __builtin_amdgcn_sched_barrier(0);
+          // t = (plane -+ delta - o) / d as one FMA per plane: plane * (1/d) - (o +- delta) * (1/d).  The rounding of
+          // the two products is an error of ~6e-8 of the plane's coordinate in space, far inside delta.
+          const float t0x = __builtin_fmaf(bx[0], cull_inv.x, cull_klo.x), t1x = __builtin_fmaf(bx[3], cull_inv.x, cull_khi.x);
+          const float t0y = __builtin_fmaf(bx[1], cull_inv.y, cull_klo.y), t1y = __builtin_fmaf(bx[4], cull_inv.y, cull_khi.y);
+          const float t0z = __builtin_fmaf(bx[2], cull_inv.z, cull_klo.z), t1z = __builtin_fmaf(bx[5], cull_inv.z, cull_khi.z);
+          const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+          const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+          mask |= fmaxf(lo0, en) <= fminf(hi0, le) ? 1u << i : 0u;
+        }
+        if (!live) mask = 0u;  // a lane without a ray of its own only helps
+        RTMI_STAT2(const unsigned long long tc1 = stat_now(); st.cyc[5] += tc1 - tc0;)
+        RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
+        {
+          // ---- the candidates of all 64 rays are worked off by all 64 lanes.  A ray comes near 2.2 pairs on
+          // average but the unluckiest of 64 near 6, and a lane-by-lane loop runs as long as that one.  So
+          // (a) every lane writes its ray and one task per candidate pair to LDS (offsets: prefix sum of the
+          // candidate counts by bit planes), (b) lane l takes task l, l + 64, ...: reads that ray and that
+          // pair's corners and runs BOTH triangle tests against the ray's t_to at the start of the chunk,
+          // (c) every lane folds the results of its own candidates in list order with its running t_to:
+          // a test that passed against the older, larger t_to passes now iff its t <= the current one,
+          // which is the only place t_to enters the test (utils.cu:74).
+          constexpr int RW = (F & F_TEX) ? 6 : 2;  // result words per task: t of the two triangles (+ their u, v)
+          int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks;
+          const int cnt = __builtin_popcount(mask);
+          int base = 0;
+#pragma unroll
+          for (int bit = 0; bit < 6; bit++)
+            base += lane_rank(__builtin_amdgcn_ballot_w64(((cnt >> bit) & 1) != 0)) << bit;
+          if (cnt != 0) {
+            int *rr = ll + lane * 8;
+            int w3 = 0, w7 = 0;
+            if (DT) {
+              const double td = (double)t_to;
+              w3 = __double2loint(td), w7 = __double2hiint(td);
+            } else {
+              w3 = __float_as_int((float)t_to);
+            }
+            *reinterpret_cast<int4 *>(rr) = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), w3);
+            *reinterpret_cast<int4 *>(rr + 4) = make_int4(__float_as_int(d.x), __float_as_int(d.y), __float_as_int(d.z), w7);
+          }
+          bool todo = cnt != 0;
+          while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+            RTMI_STAT(st.cull_iters++;)
+            const int lo_t = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
+            const bool now = todo && base + cnt - lo_t <= kListTasks;
+            const int n_now = __builtin_amdgcn_readlane(base + cnt, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo_t;
+            if (now) {  // (a)
+              int k = base - lo_t;
+              for (uint32_t m = mask; m != 0u; m &= m - 1u) tasks[k++] = (lane << 5) | __builtin_ctz(m);
+            }
+            wave_lds_fence();
+            for (int t0 = 0; t0 < n_now; t0 += 64) {  // (b)
+              const int ti = t0 + lane;
+              if (ti < n_now) {
+                const int w = tasks[ti];
+                const int *orr = ll + (w >> 5) * 8;
+                const float4 r0 = *reinterpret_cast<const float4 *>(orr), r1 = *reinterpret_cast<const float4 *>(orr + 4);
+                T t0_to;
+                if (DT) {
+                  t0_to = (T)__hiloint2double(__float_as_int(r1.w), __float_as_int(r0.w));
+                } else {
+                  t0_to = (T)r0.w;
+                }
+                const V3 ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
+                const float4 *pp = s_pairs + (size_t)(pair0 + c0 + (w & 31)) * 4;
+                const float4 qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
+                float ta = 0.f, ua = 0.f, va = 0.f, tb = 0.f, ub = 0.f, vb = 0.f;
+                const V3 e1 = p1 - p0, e2 = p2 - p0;  // utils.cu:54-55, the subtractions scene.hip: make_tri does
+                const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(rd, e2), ro, rd, t0_to, ta, ua, va);
+                bool hit_b = false;
+                if (__float_as_int(qd.x) & PAIR_SECOND) {
+                  const V3 e1b = p2 - p1, e2b = p3 - p1;
+                  hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(rd, e2b), ro, rd, t0_to, tb, ub, vb);
+                }
+                int *res = results + ti * RW;
+                res[0] = hit_a ? __float_as_int(ta) : (int)0xffffffff;  // (a NaN pattern no t can have)
+                res[1] = hit_b ? __float_as_int(tb) : (int)0xffffffff;
+                if (F & F_TEX) {
+                  res[2] = __float_as_int(ua), res[3] = __float_as_int(va), res[4] = __float_as_int(ub), res[5] = __float_as_int(vb);
+                }
+              }
+            }
+            wave_lds_fence();
+            RTMI_STAT2(const unsigned long long tc2 = stat_now();)
+            if (now) {  // (c)
+              int k = base - lo_t;
+              for (uint32_t m = mask; m != 0u; m &= m - 1u, k++) {
+                const int tri = run.first + 2 * (c0 + __builtin_ctz(m));
+                const int *res = results + k * RW;
+                const int ia = res[0], ib = res[1];
+                const float ta = __int_as_float(ia), tb = __int_as_float(ib);
+                // parallelogram.cu:25-33 with the t_to of THIS moment: the first triangle, else the second
+                const bool hit_a = ia != (int)0xffffffff && (T)ta <= t_to;
+                const bool hit_b = !hit_a && ib != (int)0xffffffff && (T)tb <= t_to;
+                const float t = hit_a ? ta : tb;
+                const bool acc = (hit_a || hit_b) && (!ok || (T)t < t_to);
+                ok = ok || acc;
+                t_to = acc ? (T)t : t_to;
+                win = acc ? make_id(RUN_TRIS, tri + (hit_a ? 0 : 1)) : win;
+                if (F & F_TEX) {
+                  bu = acc ? __int_as_float(hit_a ? res[2] : res[4]) : bu;
+                  bv = acc ? __int_as_float(hit_a ? res[3] : res[5]) : bv;
+                }
+              }
+              todo = false;
+            }
+            wave_lds_fence();
+            RTMI_STAT2(st.cyc[7] += stat_now() - tc2;)
+          }
+        }
+        RTMI_STAT2(st.cyc[6] += stat_now() - tc1;)  // (a) + (b) + (c); [7] is (c) alone
+      }
+    } else if ((F & F_TRIS) && live && run.kind == RUN_TRIS) {
+      // Plain scan (lists too long for the LDS staging of the culled one).
+      // Records come in (first, second) pairs: a Parallelogram's two triangles, or a lone
+      // Triangle followed by an inert record.  Two SGPR buffers ping-pong: while record A
+      // is tested the fetch of B is in flight, and vice versa.  Scalar-memory waits are
+      // all-or-nothing (lgkmcnt counts SMEM out of order), so the order is pinned: wait
+      // for the buffer about to be used, only then issue the next fetch, then test.
+      const HotTri *base = sc.tris + run.first;
+      f32x16 A = load_hot_tri(base, 0);
+      for (int i = 0; i < run.count; i++) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): A has landed
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x16 B = load_hot_tri(base, 2 * i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        float t = 0.f, u = 0.f, v = 0.f;
+        const V3 pv_a = cross3(d, mk(A[6], A[7], A[8]));
+        const bool hit_a = tri_test_flat<T>(mk(A[0], A[1], A[2]), mk(A[3], A[4], A[5]), mk(A[6], A[7], A[8]), pv_a, o, d,
+                                            t_to, t, u, v);
+        {
+          bool acc = hit_a && (!ok || (T)t < t_to);
+          ok = ok || acc;
+          t_to = acc ? (T)t : t_to;
+          win = acc ? make_id(RUN_TRIS, run.first + 2 * i) : win;
+          if (F & F_TEX) {
+            bu = acc ? u : bu;
+            bv = acc ? v : bv;
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // B has landed
+        __builtin_amdgcn_sched_barrier(0);
+        A = load_hot_tri(base, 2 * i + 2);  // next pair (or the inert padding pair)
+        __builtin_amdgcn_sched_barrier(0);
+        if (__float_as_int(B[13]) & TRI_SECOND) {  // wave-uniform: a lone Triangle has no second record
+          // parallelogram.cu:33: the second triangle is tried only when the first missed
+          V3 pv_b = pv_a;
+          if (!(__float_as_int(B[13]) & TRI_SAME_E2)) pv_b = cross3(d, mk(B[6], B[7], B[8]));  // wave-uniform
+          bool hit_b = tri_test_flat<T>(mk(B[0], B[1], B[2]), mk(B[3], B[4], B[5]), mk(B[6], B[7], B[8]), pv_b, o, d,
+                                        t_to, t, u, v);
+          hit_b = hit_b && !hit_a;
+          bool acc = hit_b && (!ok || (T)t < t_to);
+          ok = ok || acc;
+          t_to = acc ? (T)t : t_to;
+          win = acc ? make_id(RUN_TRIS, run.first + 2 * i + 1) : win;
+          if (F & F_TEX) {
+            bu = acc ? u : bu;
+            bv = acc ? v : bv;
+          }
+        }
+      }
+    }
+    if ((F & F_SPHERE) && live && run.kind == RUN_SPHERE) {
+      f32x8 nxt = load_sphere(sc.spheres, run.first);
+      for (int i = 0; i < run.count; i++) {
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the triangle loop
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x8 cur = nxt;
+        nxt = load_sphere(sc.spheres, run.first + i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const double r2 = __hiloint2double(__float_as_int(cur[7]), __float_as_int(cur[6]));
+        V3 oc = o - mk(cur[0], cur[1], cur[2]);
+        const float bf = 2.0f * dot3(d, oc);
+        {
+          // Wave-level cull.  The reference's discriminant is b*b - 4*a*c in double from the
+          // binary32 values b, a = |d|^2, |oc|^2 (sphere.cu:13-17).  The same expression in
+          // binary32 (with dot(oc,oc) for |oc|^2, i.e. without the square root) is off by at
+          // most a few ulp of its largest term; when it is below -1e-5 of the terms' magnitude
+          // on EVERY lane the exact discriminant is negative on every lane, no lane can hit, and
+          // the binary64 part is skipped.  Lanes of a wave carry unrelated rays, but a small
+          // sphere is in the way of few of them.  (NaN/inf compare false: not skipped.)
+          const float oc2 = dot3(oc, oc), r2f = (float)r2;
+          const float disc_f = bf * bf - 4.0f * saf * (oc2 - r2f);
+          const float mag = bf * bf + 4.0f * saf * (oc2 + r2f);
+          if (!__any(!(disc_f < -1e-5f * mag))) continue;
+        }
+        double b = (double)bf;
+        float lc = len3(oc);
+        double c = (double)(lc * lc) - r2;
+        double disc = b * b - 4 * sa * c;
+        bool hit = false;
+        double t = 0.0;
+        if (!(disc < 0)) {
+          double sq = sqrt(disc);
+          t = (-b - sq) / sa2;
+          hit = (1e-3 <= t && t <= (double)t_to);
+          if (!hit) {
+            t = (-b + sq) / sa2;
+            hit = (1e-3 <= t && t <= (double)t_to);
+          }
+        }
+        bool acc = hit && (!ok || t < (double)t_to);
+        ok = ok || acc;
+        t_to = acc ? (T)t : t_to;
+        win = acc ? make_id(RUN_SPHERE, run.first + i) : win;
+      }
+    }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 3
+    if (false) {
+#else
+    if ((F & F_BVH) && run.kind == RUN_BVH) {
+#endif
+      // BVH::Hit (bvh.cuh:123-183) answered without walking the reference's tree.
+      //
+      // What the reference computes: a depth-first walk, left subtree first, with a running
+      // t_to; a child is entered iff AABB::Hit(child box, [t_from, t_to]) holds at that moment
+      // (the root's box is never tested); an entered leaf scans its faces in order, accepts
+      // every t_from <= t <= t_to and lowers t_to to it; the last acceptance is the answer.
+      // Hence (DESIGN.md "Mesh queries"):
+      //  * a leaf's contribution at running bound T is its best face -- smallest t, highest
+      //    reference index among equal t -- provided that t <= T; it does not depend on T
+      //    otherwise, nor on the order the faces are looked at;
+      //  * leaves without a hit change nothing; whether their boxes were entered is irrelevant;
+      //  * a box test is only ever needed on the root-to-leaf path of a leaf that holds a hit,
+      //    and it sees the t_to left by the hit leaves before it in visiting order.
+      // So: (1) one search of the mesh-wide 4-wide tree (mesh_search: by the whole wave, for all
+      // its rays at once) collects, per reference leaf, the best face in the ray's small list
+      // keyed by the leaf's path code; (2) each lane replays its listed leaves in visiting order,
+      // evaluating the reference's exact box test on the path nodes not shared with the previously
+      // replayed leaf.  If more leaves hold hits than the list has slots, the leaves beyond `cut`
+      // are left to a further search pass.
+      const V3 inv_d = mk(safe_inverse(d.x), safe_inverse(d.y), safe_inverse(d.z));
+      int *rr = wl + lane * kMeshRayWords;
+      for (int i = 0; i < run.count; i++) {
+        BvhRec br;
+        {
+          const i32x8 bw = load_bvh_rec(sc.bvhs, run.first + i);  // wave-uniform: scalar load
+          br.root = bw[0], br.mat = bw[1], br.has_uv = bw[2], br.face_base = bw[3], br.sub_root = bw[4];
+          br.mag = __int_as_float(bw[5]);
+          br.ref_depth = bw[6], br.path_base = bw[7];
+        }
+        T bt_to = t_to;
+        bool bhit = false;
+        int bface = 0;
+        float fu = 0.f, fv = 0.f;
+        // replay state: path code of the last replayed leaf and, left-aligned like the code,
+        // one bit per level "that node of its path was entered"
+        bool have_prev = false;
+        uint32_t prev_code = 0u, entered = 0u;
+        uint32_t lo_code = 0u;
+        bool need = live;
+        // All 64 lanes walk this loop together (lanes without a ray with need == false): the search
+        // is the wave's.
+        while (__ballot(need) != 0ull) {
+          // ---- (1) search: best face per leaf with lo_code <= code < cut, t <= bt_to
+          RTMI_STAT(const unsigned long long ts0 = stat_now();)
+          mesh_search<T, DT>(sc, br.sub_root, sc.tops + (size_t)(run.first + i) * kTopEntries, br.mag, wl, need, o, d, inv_d,
+                             bt_to, lo_code, overflow
+#ifdef RTMI_STATS
+                             , st
+#endif
+          );
+          RTMI_STAT(const unsigned long long ts1 = stat_now(); st.cyc[2] += ts1 - ts0;)
+          // ---- (2) replay the listed leaves in the reference's visiting order.  The box tests are
+          // spread over the wave: AABB::Hit(box, [t_from, T]) is `crossing time <= T` with a crossing time
+          // that does not depend on T (aabb_crossing_time), so (a) every lane with listed leaves writes one
+          // word per leaf (its lane, the leaf's row in the mesh's path table) into the search's (now empty)
+          // stack, (b) all 64 lanes work off the (leaf, level) pairs, whoever's they are: node from the path
+          // table, its box, that ray, the crossing time, (c) each lane walks its leaves with the running
+          // t_to, looking the crossing times up.  A lane whose leaves do not fit next to the others' waits
+          // for the next round.
+          RTMI_STAT(const unsigned long long tr0 = stat_now(); (void)tr0;)
+          uint32_t cut = kCodeNone;
+          int cnt = 0;
+          int4 hs[kHitSlots];  // my entries: leaf, face, t
+#pragma unroll
+          for (int j = 0; j < kHitSlots; j++) hs[j] = make_int4((int)kCodeNone, 0, 0, 0);
+          if (need) {
+            const int4 head = *reinterpret_cast<const int4 *>(rr + 12);
+            cnt = head.x, cut = (uint32_t)head.y;
+            const int4 wa = *reinterpret_cast<const int4 *>(rr + 16), wb = *reinterpret_cast<const int4 *>(rr + 20),
+                       wc = *reinterpret_cast<const int4 *>(rr + 24);
+            const int4 e4[kHitSlots] = {make_int4(wa.x, wa.y, wa.z, 0), make_int4(wa.w, wb.x, wb.y, 0),
+                                        make_int4(wb.z, wb.w, wc.x, 0), make_int4(wc.y, wc.z, wc.w, 0)};
+#pragma unroll
+            for (int j = 0; j < kHitSlots; j++)
+              if (j < cnt && (uint32_t)e4[j].x < cut) hs[j] = e4[j];  // (the rest was pushed beyond `cut`: next pass)
+          }
+          // ... in visiting order = by ascending leaf ordinal (never kCodeNone): a five-exchange network
+#define RTMI_ORDER(A, B)                                        \
+  {                                                             \
+    const bool sw = (uint32_t)hs[B].x < (uint32_t)hs[A].x;      \
+    const int4 lo_ = sw ? hs[B] : hs[A], hi_ = sw ? hs[A] : hs[B]; \
+    hs[A] = lo_, hs[B] = hi_;                                   \
+  }
+          RTMI_ORDER(0, 1) RTMI_ORDER(2, 3) RTMI_ORDER(0, 2) RTMI_ORDER(1, 3) RTMI_ORDER(1, 2)
+#undef RTMI_ORDER
+          int nleaf = 0;
+#pragma unroll
+          for (int j = 0; j < kHitSlots; j++) nleaf += (uint32_t)hs[j].x != kCodeNone ? 1 : 0;
+          const int depth_r = br.ref_depth;
+          const int log_d = depth_r < 8 ? 3 : depth_r < 16 ? 4 : 5;  // a leaf's row: its path code + the crossing times, 8, 16 or 32 words
+          const int rows_max = (kMeshStackWords - 64) >> log_d;
+          // exclusive prefix sum of nleaf (0..4) over the wave, bit plane by bit plane: no LDS round trips
+          const int base = lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 1) != 0)) +
+                           2 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 2) != 0)) +
+                           4 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 4) != 0));
+          int *leaves = wl + 64 * kMeshRayWords;  // [64] one word per listed leaf of this round
+          int *times = leaves + 64;                // rows of crossing times
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 4
+          bool todo = false;  // (diagnostic: no replay, nearest listed hit)
+#else
+          bool todo = nleaf > 0 && depth_r > 0;
+#endif
+          RTMI_STAT3(unsigned long long tr1 = stat_now(); st.cyc[5] += tr1 - ts1;)
+          while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+            const int lo = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
+            const bool now = todo && base + nleaf - lo <= rows_max;
+            const int n_rows = __builtin_amdgcn_readlane(base + nleaf, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo;
+            if (now) {  // (a)
+#pragma unroll
+              for (int k = 0; k < kHitSlots; k++)
+                if (k < nleaf) leaves[base - lo + k] = (lane << 26) | hs[k].x;
+            }
+            wave_lds_fence();
+            RTMI_STAT3(const unsigned long long tr2 = stat_now(); st.cyc[6] += tr2 - tr1;)
+            // (b) crossing times, one (leaf, level) per lane and round
+            const int n_now = n_rows << log_d;
+            for (int t0 = 0; t0 < n_now; t0 += 64) {
+              const int t = t0 + lane, lvl = t & ((1 << log_d) - 1);  // word 0 of a row: the leaf's path code
+              if (t < n_now && lvl <= depth_r) {
+                const int w = leaves[t >> log_d];
+                const int pi = br.path_base + (w & (kMeshMaxNodes - 1)) * (depth_r + 1) + lvl;
+                const int ni = pi < lds_paths ? s_paths[pi] : sc.leaf_paths[pi];
+                float m = __int_as_float(lvl == 0 ? ni : (int)0xffffffff);  // marker: past the leaf
+                if (lvl != 0 && ni >= 0) {
+                  const int *orr = wl + (int)((unsigned)w >> 26) * kMeshRayWords;
+                  const float4 r0 = *reinterpret_cast<const float4 *>(orr + 0), r1 = *reinterpret_cast<const float4 *>(orr + 4);
+                  BvhNode nd;
+                  if (ni < lds_nodes) {
+                    nd = s_nodes[ni];
+                  } else {
+                    nd = sc.nodes[ni];
+                  }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 5
+                  m = nd.mn[0] * r0.x + r1.x;  // (diagnostic: the loads without the arithmetic)
+#else
+                  m = aabb_crossing_time(nd, mk(r0.x, r0.y, r0.z), mk(r1.x, r1.y, r1.z));
+#endif
+                }
+                times[t] = __float_as_int(m);
+              }
+            }
+            wave_lds_fence();
+            RTMI_STAT3(const unsigned long long tr3 = stat_now(); st.cyc[7] += tr3 - tr2;)
+            // (c) the walk of bvh.cuh:123-158 over my leaves
+            // (c) the walk of bvh.cuh:123-158 over my leaves, without branches: per leaf one bit per level,
+            // left-aligned like the path code -- `valid` the levels of its path (a prefix), `pass` the levels whose
+            // box is entered: as the previous leaf found it where the two paths coincide, by `crossing time <=
+            // t_to` below.  The walk stops at the first level that is not entered; the leaf's faces count iff
+            // there is none.
+            if (__builtin_amdgcn_ballot_w64(now) != 0ull) {
+#pragma unroll
+              for (int k = 0; k < kHitSlots; k++) {
+                if (__builtin_amdgcn_ballot_w64(now && k < nleaf) == 0ull) break;  // wave-uniform
+                const bool mine = now && k < nleaf;
+                const int *row = times + (mine ? (base - lo + k) << log_d : 0);
+                uint32_t code = 0u, valid = 0u, below = 0u;
+                for (int c = 0; c <= depth_r; c += 8) {  // wave-uniform trip count
+                  const int4 ma = *reinterpret_cast<const int4 *>(row + c), mb = *reinterpret_cast<const int4 *>(row + c + 4);
+                  const int mv[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+                  if (c == 0) code = (uint32_t)ma.x;
+#pragma unroll
+                  for (int j = 0; j < 8; j++) {
+                    const uint32_t bit = 0x80000000u >> ((c + j - 1) & 31);  // level c + j (>= 1)
+                    const bool in_row = c + j >= 1 && c + j <= depth_r;
+                    valid |= in_row && mv[j] != (int)0xffffffff ? bit : 0u;
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 1
+                    below |= in_row ? bit : 0u;
+#else
+                    below |= in_row && (T)__int_as_float(mv[j]) <= bt_to ? bit : 0u;  // (the marker is a NaN: false)
+#endif
+                  }
+                }
+                const int shared = have_prev ? __clz((int)(prev_code ^ code)) : 0;  // decisions in common
+                const uint32_t common = shared ? 0xffffffffu << (32 - shared) : 0u;
+                const uint32_t pass = (entered & common) | (below & ~common);
+                const uint32_t fail = valid & ~pass;
+                const int upto = fail ? __clz((int)fail) : __popc(valid);  // levels entered before the walk stopped
+                const uint32_t walked = upto ? 0xffffffffu << (32 - upto) : 0u;
+                const uint32_t bits = (entered & common) | (walked & ~common);
+                if (mine) {
+                  have_prev = true;
+                  prev_code = code;
+                  entered = bits;
+                  const T tj = (T)__int_as_float(hs[k].z);
+                  if (fail == 0u && tj <= bt_to) {
+                    bt_to = tj;
+                    bhit = true;
+                    bface = hs[k].y;
+                  }
+                }
+              }
+              if (now) todo = false;
+            }
+            wave_lds_fence();
+            RTMI_STAT3(tr1 = stat_now(); st.cyc[8] += tr1 - tr3;)
+          }
+#if defined(RTMI_ABLATE) && RTMI_ABLATE == 4
+          if (nleaf > 0) {
+#else
+          if (nleaf > 0 && depth_r == 0) {  // the root is the only leaf: nothing to test (its box never is)
+#endif
+#pragma unroll
+            for (int k = 0; k < kHitSlots; k++) {
+              if (k < nleaf) {
+                const T tj = (T)__int_as_float(hs[k].z);
+                if (tj <= bt_to) bt_to = tj, bhit = true, bface = hs[k].y;
+              }
+            }
+          }
+          need = need && cut != kCodeNone;  // leaves were deferred: search again from `cut` on
+          lo_code = cut;
+          RTMI_STAT(st.cyc[3] += stat_now() - ts1;)
+        }
+        if (bhit && (F & F_TEX)) {
+          // barycentrics of the winner (the same binary32 operations as in the search)
+          const FaceRec f = sc.faces[bface];
+          float t = 0.f;
+          const V3 fe2 = mk(f.e2[0], f.e2[1], f.e2[2]);
+          (void)tri_test_flat<T>(mk(f.p0[0], f.p0[1], f.p0[2]), mk(f.e1[0], f.e1[1], f.e1[2]), fe2, cross3(d, fe2), o, d,
+                                 bt_to, t, fu, fv);
+        }
+        bool acc = bhit && (!ok || bt_to < t_to);
+        ok = ok || acc;
+        t_to = acc ? bt_to : t_to;
+        win = acc ? make_id(RUN_BVH, bface) : win;
+        aux = acc ? run.first + i : aux;
+        bu = acc ? fu : bu;
+        bv = acc ? fv : bv;
+      }
+    }
+  }
+  Hit h;
+  h.ok = ok;
+  h.t = (float)t_to;
+  h.win = win;
+  h.aux = aux;
+  h.u = bu;
+  h.v = bv;
+  return h;
+}

@@ -1,0 +1,471 @@
+// The persistent per-pixel trace loop.  Included by kernels.hip inside namespace rtmi, after closest_hit.h
+// (not a stand-alone header).
+#pragma once
+
+// ================================================================== trace kernel
+// Dynamic LDS: [ material records: lds_mats * 32 B ][ id stack: max_depth * blockDim entries ]
+// The id stack is laid out [depth][thread] so the lanes of a wave touch consecutive
+// bytes; entries are 4 bits when there are at most 16 materials (two levels per byte, lc.wide_ids == 2:
+// half the LDS, which is what lets a sixth wave per SIMD of the list kernel in at depth 50), uint8 when
+// every material id fits a byte, else uint16 (lc.wide_ids == 1).
+struct LaunchCfg {
+  int32_t lds_mats;    // materials staged in LDS (0: read them from global memory)
+  int32_t wide_ids;    // 0: uint8 stack entries, 1: uint16, 2: 4-bit (two levels per byte)
+  int32_t stack_off;   // byte offset of the id stack inside dynamic LDS
+  int32_t nodes_off;   // byte offset of the staged reference-tree nodes
+  int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
+  int32_t mesh_off;    // byte offset of the per-wave mesh-search regions (kMeshWaveWords words each; BVH variants)
+  int32_t exclusive;   // 1: while a wave holds an outlier pixel, its other lanes take no new pixels (they work for it)
+  int32_t pairs_off;   // byte offset of the staged PairPts records, -1: not staged (plain list scan)
+  int32_t list_off;    // byte offset of the per-wave regions of the shared candidate tests, -1: each lane tests its own
+  int32_t paths_off;   // byte offset of the staged leaf-path words
+  int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
+  int32_t pad2[1];
+  const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
+  const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
+  int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
+};
+
+template <uint32_t F>
+__device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &fr, const LaunchCfg &lc,
+                                            uint32_t *__restrict__ states, float *__restrict__ out,
+                                            uint32_t *__restrict__ ray_counts,
+                                            unsigned long long *__restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
+  // id stack: byte offset of entry [level][thread] in LDS, kept as 32-bit arithmetic (pointer
+  // arithmetic on the generic pointers costs a register pair per live address)
+  const uint32_t ids_shift = lc.wide_ids == 1 ? 1u : 0u;
+  const bool nibble_ids = lc.wide_ids == 2;
+  auto ids_offset = [&](int level) -> uint32_t {  // (nibble_ids: the byte of levels 2k and 2k + 1 is row k)
+    return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << ids_shift);
+  };
+  const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
+  int *wl = nullptr;  // this wave's mesh-search region
+  if (F & F_BVH)
+    wl = reinterpret_cast<int *>(smem + lc.mesh_off) +
+         __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kMeshWaveWords;
+  const float4 *s_pairs = nullptr;  // corners of the world-list pairs (culled scan) or nullptr (plain scan)
+  if ((F & F_TRIS) && lc.pairs_off >= 0) {
+    s_pairs = reinterpret_cast<const float4 *>(smem + lc.pairs_off);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.pair_pts);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.pairs_off);
+    for (int w = threadIdx.x; w < sc.n_pairs * 16; w += blockDim.x) dst[w] = src[w];
+  }
+  int *ll = nullptr;  // this wave's region for the shared candidate tests of the culled list scan
+  if ((F & F_TRIS) && lc.list_off >= 0)
+    ll = reinterpret_cast<int *>(smem + lc.list_off) +
+         __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * 8 + kListTasks * (1 + ((F & F_TEX) ? 6 : 2)));
+  const bool mats_in_lds = lc.lds_mats > 0;
+  const bool fast_fold = mats_in_lds && lc.wide_ids != 1 && sc.unsigned_colours;  // see the radiance fold
+  if (mats_in_lds) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(s_mats);
+    for (int w = threadIdx.x; w < lc.lds_mats * 8; w += blockDim.x) dst[w] = src[w];
+  }
+  if ((F & F_BVH) && lc.lds_nodes > 0) {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.nodes);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.nodes_off);
+    for (int w = threadIdx.x; w < lc.lds_nodes * 8; w += blockDim.x) dst[w] = src[w];
+  }
+  const int *s_paths = reinterpret_cast<const int *>(smem + lc.paths_off);
+  if ((F & F_BVH) && lc.lds_paths > 0) {
+    int *dst = reinterpret_cast<int *>(smem + lc.paths_off);
+    for (int w = threadIdx.x; w < lc.lds_paths; w += blockDim.x) dst[w] = sc.leaf_paths[w];
+  }
+  __syncthreads();
+
+  const int64_t n_items = fr.items;
+  const bool w_pow2 = (fr.width & (fr.width - 1)) == 0, h_pow2 = (fr.height & (fr.height - 1)) == 0;
+  const double inv_w = 1.0 / (double)fr.width, inv_h = 1.0 / (double)fr.height;
+  // per-lane pixel state
+  int64_t q = 0;
+  int pi = 0, pj = 0, k = 0;
+  bool has_px = false, done = false, active = false;
+  bool heavy = false;  // a pixel of the queue's sparse head (see below)
+  V3 color = splat(0.f);
+  uint32_t rays = 0;
+  unsigned long long ray_total = 0;
+  Rng rng = {0, 0, 0, 0, 0, 0};
+  // per-lane path state
+  V3 o = splat(0.f), d = splat(0.f);
+  int depth = 0;
+  // Layer stack of ray_tracing.cuh:9-15.  Layer::emitted is 0 for every material that
+  // scatters (only DiffuseLight and Sky emit, and neither scatters), so a layer is its
+  // attenuation.  Without image textures the attenuation is the material's constant
+  // colour and the layer is stored as a material id in LDS; with image textures the
+  // sampled colour itself is kept (private memory).
+  constexpr int kAttFloats = (F & F_TEX) ? RTMI_KERNEL_MAX_DEPTH * 3 : 3;
+  float att[kAttFloats];
+
+  // Mesh variants, frames dominated by a few outlier tiles (their pixels bounce to the depth limit
+  // inside the mesh, tens of times the median cost): the frame time is the serial chain of the
+  // slowest pixel, and what shortens a chain is the wave-cooperative search, which needs few rays
+  // per wave.  The first sparse_limit work items (the outlier tiles, longest-first order) are
+  // therefore spread thin -- one pixel per lc.sparse_stride lanes -- while the rest of the frame runs
+  // with full waves.
+  unsigned long long sparse_limit = 0ull;
+  if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
+  auto take_item = [&](int64_t item) -> bool {  // false: ragged-tile padding (or nothing to sample), written as black
+    q = item;
+    int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
+    if (idx < 0 || fr.spp <= 0) {
+      out[q * 3 + 0] = 0.f, out[q * 3 + 1] = 0.f, out[q * 3 + 2] = 0.f;
+      if (ray_counts) ray_counts[q] = 0;
+      return false;
+    }
+    pi = (int)(idx / fr.width);
+    pj = (int)(idx % fr.width);
+    rng.d = states[0 * n_items + q];
+    rng.v0 = states[1 * n_items + q];
+    rng.v1 = states[2 * n_items + q];
+    rng.v2 = states[3 * n_items + q];
+    rng.v3 = states[4 * n_items + q];
+    rng.v4 = states[5 * n_items + q];
+    k = 0;
+    rays = 0;
+    color = splat(0.f);
+    has_px = true;
+    return true;
+  };
+
+  RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();)
+  for (;;) {
+    RTMI_STAT(const unsigned long long tq0 = stat_now();)
+    // -------------------------------------------------------- sample / pixel bookkeeping
+    if (!active && !done && has_px && k >= fr.spp) {
+      V3 c = color;
+      if (fr.post) {  // ray_tracing.cu:78-83
+        c = c / (float)fr.spp;
+        c = mk(clamp1(c.x, 0.f, 1.f), clamp1(c.y, 0.f, 1.f), clamp1(c.z, 0.f, 1.f));
+        c = mk(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
+      }
+      out[q * 3 + 0] = c.x;
+      out[q * 3 + 1] = c.y;
+      out[q * 3 + 2] = c.z;
+      if (ray_counts) ray_counts[q] = rays;
+      ray_total += rays;
+      states[0 * n_items + q] = rng.d;
+      states[1 * n_items + q] = rng.v0;
+      states[2 * n_items + q] = rng.v1;
+      states[3 * n_items + q] = rng.v2;
+      states[4 * n_items + q] = rng.v3;
+      states[5 * n_items + q] = rng.v4;
+      has_px = false;
+    }
+    const bool wave_heavy = (F & F_BVH) && lc.exclusive &&
+                            __builtin_amdgcn_ballot_w64(has_px && heavy && (active || k < fr.spp)) != 0ull;
+    if (!active && !done) {
+      while (!has_px && !done) {
+        if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (uint32_t)(lc.sparse_stride - 1)) != 0) {
+          if (wave_heavy) break;  // this wave is busy with an outlier pixel: stay a helper
+          // the head of the queue holds the outlier tiles: only every sparse_stride-th lane takes
+          // pixels there (the others look again next round), so that a wave carries few rays
+          // and the mesh search runs in its cooperative mode
+          if (__hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sparse_limit) break;
+        }
+        const unsigned long long nq = atomicAdd(&counters[0], 1ull);
+        if ((int64_t)nq >= n_items) {
+          done = true;
+          break;
+        }
+        int64_t item = (int64_t)nq;
+        if (lc.tile_order) item = (int64_t)lc.tile_order[nq >> 6] * 64 + (int64_t)(nq & 63);
+        if (!take_item(item)) continue;
+        heavy = nq < sparse_limit;
+      }
+      if (has_px) {
+        // ray_tracing.cu:68-74 + camera.cu:57-70
+        float r1 = rng_01(rng);
+        float r2 = rng_01(rng);
+        // division by a power of two is an exact scaling: multiply by the (exact) reciprocal
+        double x = (double)r1 + (double)pj;
+        double y = (double)r2 + (double)(fr.height - pi);
+        x = w_pow2 ? x * inv_w : x / (double)fr.width;
+        y = h_pow2 ? y * inv_h : y / (double)fr.height;
+        x = 2 * x - 1;
+        y = 2 * y - 1;
+        x = (x + 1) / 2;
+        y = (y + 1) / 2;
+        V3 target = sc.cam.llc + (float)x * sc.cam.horizontal + (float)y * sc.cam.vertical;
+        V3 origin = sc.cam.position;
+        if (F & F_DEFOCUS) {
+          if (sc.cam.defocus) {  // camera.cu:63-65,74-77 (a square, drawn left to right)
+            float ox = rng_range(0.f, sc.cam.lens_radius, rng);
+            float oy = rng_range(0.f, sc.cam.lens_radius, rng);
+            origin = sc.cam.position + sc.cam.u * ox + sc.cam.v * oy;
+          }
+        }
+        o = origin;
+        d = unit3_rn(unit3_rn(target - origin));  // RayAt normalises, Ray's constructor normalises again
+        k++;
+        depth = 0;
+        active = true;
+      }
+    }
+    if (!__any(active)) {
+      if (!(F & F_BVH) || __all(done)) break;
+      continue;  // lanes held back from the sparse head of the queue: it has just moved on
+    }
+
+    RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
+              const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
+    Hit h = {};
+    const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && s_pairs != nullptr);  // wave-uniform
+    if (all_lanes_in)  // every lane goes in, with or without a ray of its own: see closest_hit
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, wl, counters + 2, o, d, active
+#ifdef RTMI_STATS
+                         , st
+#endif
+      );
+    RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
+    if (active) {
+      if (!all_lanes_in)
+        h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, o, d, true
+#ifdef RTMI_STATS
+                           , st
+#endif
+        );
+      rays++;
+
+      V3 result = splat(0.f);
+      bool ended = true;
+      if (h.ok && depth < fr.max_depth) {  // ray_tracing.cu:23
+        const uint32_t kind = h.win >> 29;
+        const uint32_t index = h.win & ID_INDEX_MASK;
+        V3 p = o + h.t * d;  // ray_tracing.cu:32 and the materials' own `p`
+        if (kind == RUN_SKY) {
+          // sky.cu:9-14: Scatter false; Emit(p) = gradient on normalize(p)
+          V3 dir = unit3_rn(p);
+          float tg = (float)(0.5 * ((double)dir.y + 1.0));
+          float w0 = 1.0f - tg;
+          result = mk(w0 * 1.0f + tg * 0.5f, w0 * 1.0f + tg * 0.7f, w0 * 1.0f + tg * 1.0f);
+        } else {
+          V3 nrm = splat(0.f);
+          int mat = 0;
+          float tu = 0.f, tv = 0.f;  // record.u, record.v (only read by image textures)
+          if ((F & F_TRIS) && kind == RUN_TRIS) {
+            const HotTri &tr = sc.tris[index];  // per-lane gather of the winner (L1/L2 resident)
+            V3 n = mk(tr.n[0], tr.n[1], tr.n[2]);
+            nrm = dot3(d, n) < 0.f ? n : -n;  // utils.cu:80
+            mat = tr.mat;
+            if (F & F_TEX) {
+              const int flags = tr.flags;
+              if (flags & TRI_PGRAM) {  // parallelogram.cu:26-29,35-38
+                float w = (float)((1.0 - (double)h.u) - (double)h.v);
+                if (!(flags & TRI_SECOND)) {
+                  tu = (0.f * w + 1.f * h.u) + 0.f * h.v;
+                  tv = (1.f * w + 1.f * h.u) + 0.f * h.v;
+                } else {
+                  tu = (1.f * w + 0.f * h.u) + 1.f * h.v;
+                  tv = (1.f * w + 0.f * h.u) + 0.f * h.v;
+                }
+              } else {
+                tu = h.u, tv = h.v;  // triangle.cu:13
+              }
+            }
+          }
+          if ((F & F_SPHERE) && kind == RUN_SPHERE) {
+            const SphereRec &sr = sc.spheres[index];
+            nrm = unit3_rn(p - mk(sr.cx, sr.cy, sr.cz));  // sphere.cu:25-26
+            mat = sr.mat;
+            if (F & F_TEX) {  // sphere.cu:60-63
+              const float pi_f = 3.14159265358979323846264338327950288f;
+              float theta = acosf(-nrm.y);
+              float phi = atan2f(-nrm.z, nrm.x) + pi_f;
+              tu = phi / (2 * pi_f);
+              tv = theta / pi_f;
+            }
+          }
+          if ((F & F_BVH) && kind == RUN_BVH) {
+            const FaceRec &fc = sc.faces[index];
+            // utils.cu:79: normalize(cross(v0v1, v0v2)), recomputed for the winning face only
+            V3 n = unit3_rn(cross3(mk(fc.e1[0], fc.e1[1], fc.e1[2]), mk(fc.e2[0], fc.e2[1], fc.e2[2])));
+            nrm = dot3(d, n) < 0.f ? n : -n;
+            const BvhRec br = sc.bvhs[h.aux];
+            mat = br.mat;
+            if ((F & F_TEX) && br.has_uv) {  // bvh.cuh:41-45
+              const float *tc = sc.face_uv + (size_t)(br.face_base + fc.orig) * 6;
+              float w = (float)((1.0 - (double)h.u) - (double)h.v);
+              tu = (tc[0] * w + tc[2] * h.u) + tc[4] * h.v;
+              tv = (tc[1] * w + tc[3] * h.u) + tc[5] * h.v;
+            }
+          }
+          const MatRec m = mats_in_lds ? s_mats[mat] : sc.mats[mat];
+          V3 rgb = mk(m.r, m.g, m.b);
+          RTMI_STAT2(if (!(F & F_BVH)) { const unsigned long long tsa = stat_now();  // (divergent code: first active lane reports)
+            if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][9] += tsa - tq2; })
+          if (F & F_TEX) {
+            if (m.tex >= 0 && (m.kind == MAT_LAMBERTIAN || m.kind == MAT_LIGHT)) {
+              // image_texture.cu:11-13: v = 1.0 - v in double, then float coordinates
+              rgb = tex_sample(sc.texs[m.tex], tu, (float)(1.0 - (double)tv));
+            }
+          }
+          if (m.kind == MAT_LIGHT) {
+            result = rgb;  // diffuse_light.cu:5-13
+          } else {
+            const float dn = dot3(d, nrm);
+            V3 nd = splat(0.f);
+            bool scattered = false;
+            if (m.kind == MAT_LAMBERTIAN) {  // lambertian.cu:33-43
+              if (!(dn >= 0.f)) {
+                float sum;
+                V3 s = ball_sample(rng, sum);
+                const float l = sqrtf(sum);
+                s = mk(s.x / l, s.y / l, s.z / l);
+                nd = unit3_rn(s + nrm);
+                scattered = true;
+              }
+            } else if (m.kind == MAT_METAL) {  // metal.cu:12-25
+              if (!(dn >= 0.f)) {
+                V3 refl = reflect3(d, nrm);
+                if (m.param > 0.f) {
+                  float sum;
+                  V3 s = ball_sample(rng, sum);
+                  nd = refl + m.param * s;
+                } else {
+                  nd = refl;
+                }
+                scattered = true;
+              }
+            } else {  // MAT_DIELECTRIC, dielectric.cu:16-44
+              if (dn >= 0.f)
+                nd = refract3(d, -nrm, m.param / 1.0f);
+              else
+                nd = refract3(d, nrm, 1.0f / m.param);
+              bool zero = (nd.x == 0.f && nd.y == 0.f && nd.z == 0.f);
+              bool nan = (nd.x != nd.x) || (nd.y != nd.y) || (nd.z != nd.z);
+              scattered = !(zero || nan);
+            }
+            if (scattered) {
+              if (F & F_TEX) {
+                att[depth * 3 + 0] = rgb.x;
+                att[depth * 3 + 1] = rgb.y;
+                att[depth * 3 + 2] = rgb.z;
+              } else if (nibble_ids) {
+                const uint32_t at = ids_offset(depth >> 1);  // this lane's own byte: no other lane writes it
+                const uint32_t old = smem[at];
+                smem[at] = (uint8_t)((depth & 1) ? ((old & 0x0fu) | ((uint32_t)mat << 4)) : ((old & 0xf0u) | (uint32_t)mat));
+              } else if (lc.wide_ids) {
+                *reinterpret_cast<uint16_t *>(smem + ids_offset(depth)) = (uint16_t)mat;
+              } else {
+                smem[ids_offset(depth)] = (uint8_t)mat;
+              }
+              depth++;
+              o = p;
+              d = unit3_rn(nd);  // Ray's constructor
+              ended = false;
+            }
+          }
+        }
+      }
+      RTMI_STAT2(if (!(F & F_BVH)) { const unsigned long long tsb = stat_now();
+        if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][10] += tsb - tq2; })
+      if (ended) {
+        // ray_tracing.cu:50-52 with emitted == 0 on every stored layer: result = emitted +
+        // attenuation * result, deepest layer first.  The addition only matters for a product of -0,
+        // which needs a colour with its sign bit set (sc.unsigned_colours).
+        int i = depth - 1;
+        if (!(F & F_TEX) && fast_fold) {
+          // common case (byte ids, material table in LDS, no signed colours) without the per-layer
+          // uniform branches: four layers at a time, ids first, then colours, then the products
+          const uint32_t step = blockDim.x;
+          if (nibble_ids) {
+            if (i >= 0 && !(i & 1)) {  // an even top level sits alone in the low half of its byte
+              const int m0 = smem[ids_offset(i >> 1)] & 15;
+              result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+              i--;
+            }
+            for (; i >= 3; i -= 4) {  // i odd: bytes (i >> 1) and (i >> 1) - 1 hold levels i, i - 1 and i - 2, i - 3
+              const uint32_t at = ids_offset(i >> 1);
+              const uint32_t b0 = smem[at], b1 = smem[at - step];
+              const int m0 = b0 >> 4, m1 = b0 & 15, m2 = b1 >> 4, m3 = b1 & 15;
+              const V3 a0 = mk(s_mats[m0].r, s_mats[m0].g, s_mats[m0].b), a1 = mk(s_mats[m1].r, s_mats[m1].g, s_mats[m1].b);
+              const V3 a2 = mk(s_mats[m2].r, s_mats[m2].g, s_mats[m2].b), a3 = mk(s_mats[m3].r, s_mats[m3].g, s_mats[m3].b);
+              result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
+              result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
+              result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
+              result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
+            }
+            for (; i >= 1; i -= 2) {
+              const uint32_t b0 = smem[ids_offset(i >> 1)];
+              const int m0 = b0 >> 4, m1 = b0 & 15;
+              result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+              result = mk(s_mats[m1].r * result.x, s_mats[m1].g * result.y, s_mats[m1].b * result.z);
+            }
+          }
+          for (; i >= 3; i -= 4) {
+            const uint32_t at = ids_offset(i);
+            const int m0 = smem[at], m1 = smem[at - step], m2 = smem[at - 2u * step], m3 = smem[at - 3u * step];
+            const V3 a0 = mk(s_mats[m0].r, s_mats[m0].g, s_mats[m0].b), a1 = mk(s_mats[m1].r, s_mats[m1].g, s_mats[m1].b);
+            const V3 a2 = mk(s_mats[m2].r, s_mats[m2].g, s_mats[m2].b), a3 = mk(s_mats[m3].r, s_mats[m3].g, s_mats[m3].b);
+            result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
+            result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
+            result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
+            result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
+          }
+          for (; i >= 0; i--) {
+            const int m0 = smem[ids_offset(i)];
+            result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+          }
+        }
+        for (; i >= 0; i--) {
+          V3 a;
+          if (F & F_TEX) {
+            a = mk(att[i * 3 + 0], att[i * 3 + 1], att[i * 3 + 2]);
+          } else {
+            const int mi = nibble_ids     ? (int)((smem[ids_offset(i >> 1)] >> ((i & 1) * 4)) & 15u)
+                           : lc.wide_ids ? (int)*reinterpret_cast<const uint16_t *>(smem + ids_offset(i))
+                                         : (int)smem[ids_offset(i)];
+            if (mats_in_lds) {
+              a = mk(s_mats[mi].r, s_mats[mi].g, s_mats[mi].b);
+            } else {
+              a = mk(sc.mats[mi].r, sc.mats[mi].g, sc.mats[mi].b);
+            }
+          }
+          if (sc.unsigned_colours) {
+            result = mk(a.x * result.x, a.y * result.y, a.z * result.z);
+          } else {
+            result = mk(0.f + a.x * result.x, 0.f + a.y * result.y, 0.f + a.z * result.z);
+          }
+        }
+        color = color + result;
+        active = false;
+      }
+    }
+    RTMI_STAT(st.cyc[4] += stat_now() - tq2;)
+  }
+
+  // total closest-hit queries: wave reduce, one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) ray_total += __shfl_down(ray_total, off);
+  if ((threadIdx.x & 63) == 0 && ray_total) atomicAdd(&counters[1], ray_total);
+#ifdef RTMI_STATS
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned v[13] = {wave_queries, st.searches, st.node_steps, st.face_steps, st.nodes_popped, st.blocks_popped,
+                            st.insert_rounds, st.steps_hist[0], st.steps_hist[1], st.steps_hist[2], st.steps_hist[3],
+                            st.steps_hist[4], st.steps_hist[5]};
+    for (int i = 0; i < 13; i++) atomicAdd(&counters[4 + i], (unsigned long long)v[i]);
+    for (int i = 0; i < 9; i++) atomicAdd(&counters[17 + i], st.cyc[i]);
+    const unsigned long long life = stat_real() - t_begin;
+    atomicAdd(&counters[26], life);
+    atomicMax(&counters[27], life);
+    atomicAdd(&counters[28], 1ull);
+    atomicAdd(&counters[29], st.calib);
+    atomicAdd(&counters[30], st.cull_bits);
+    atomicAdd(&counters[31], st.cull_iters);
+    atomicAdd(&counters[3], st.cull_rays);
+    const unsigned wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (!(F & F_BVH) && wid < 16384u) {
+      atomicAdd(&counters[25], g_wave_stats[wid][9]);
+      atomicAdd(&counters[6], g_wave_stats[wid][10]);
+      g_wave_stats[wid][9] = 0, g_wave_stats[wid][10] = 0;
+    } else if (wid < 16384u) {
+      g_wave_stats[wid][0] = life;
+      for (int i = 0; i < 9; i++) g_wave_stats[wid][1 + i] = st.cyc[i];
+      g_wave_stats[wid][10] = wave_queries, g_wave_stats[wid][11] = st.node_steps, g_wave_stats[wid][12] = st.face_steps;
+      g_wave_stats[wid][13] = st.nodes_popped, g_wave_stats[wid][14] = st.insert_rounds;
+      g_wave_stats[wid][15] = (st.cyc[9] << 32) | (st.cyc[10] >> 8);  // setup cycles | loop-control cycles / 256
+    }
+  }
+#endif
+}

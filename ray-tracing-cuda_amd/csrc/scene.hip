@@ -368,7 +368,7 @@ static int build_subtree(std::vector<QNode4> &qn, std::vector<FacePts> &fp, int 
   return collapse4(qn, bn, root, depth);
 }
 
-// The top of a mesh's search tree as a flat table of kTopEntries sub-trees (kernels.hip, mesh_search:
+// The top of a mesh's search tree as a flat table of kTopEntries sub-trees (mesh_search.h:
 // a wave with few rays tests all of them at once instead of descending level by level).  Starting
 // from the root's children, the sub-tree with the largest surface is replaced by its children while
 // the table has room.  Boxes: the children's quantised boxes, rounded outward to binary32.
@@ -613,7 +613,7 @@ std::string Scene::flatten() {
         }
         if (br.root >= 0) br.root += node_base;
         // the leaves' root-to-leaf paths as a table: row = leaf ordinal; the leaf's path code, then ref_depth
-        // columns (the node at level 1, 2, ...), -1 below the leaf (kernels.hip, replay)
+        // columns (the node at level 1, 2, ...), -1 below the leaf (closest_hit.h, replay)
         br.path_base = (int)leaf_paths.size();
         if ((int64_t)leaf_paths.size() + (int64_t)local_paths.size() * (ref_depth + 1) > (int64_t)kLeafPathMax)
           return "mesh leaf-path table too large";

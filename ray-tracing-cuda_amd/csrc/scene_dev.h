@@ -56,7 +56,7 @@ struct HotTri {
 };
 
 // The same world-list triangles once more, per PAIR (a Parallelogram, or a lone Triangle), for the
-// culled form of the list scan (kernels.hip: closest_hit, RUN_TRIS): `PairBox` is read at a
+// culled form of the list scan (closest_hit.h: RUN_TRIS): `PairBox` is read at a
 // wave-uniform index (one s_load_dwordx8): the pair's bounds, padded like the mesh search boxes;
 // `PairPts` is staged in LDS and gathered per lane: the four corners, from which the kernel forms the
 // edges with the same binary32 subtractions the host used for HotTri.

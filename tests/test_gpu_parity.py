@@ -241,7 +241,7 @@ def test_longest_first_schedule_does_not_change_the_frame():
 
 def test_shortened_arithmetic_equals_the_reference_expressions_on_this_device():
     """Three operations of the trace loop are computed in fewer instructions than the reference's
-    expression (kernels.hip: rcp_rn for 1.0f / det, rng_pm1_of / rng_01_of for the uniform
+    expression (trace_helpers.h: rcp_rn for 1.0f / det, rng_pm1_of / rng_01_of for the uniform
     variates).  Their equality is established by exhaustion on the device itself: all 2^32 inputs
     each, zero differences (for the reciprocal: inside its stated domain)."""
     import ctypes as C

@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_float_thresholds_used_by_the_kernel():
-    """kernels.hip replaces two double compares of the reference by float compares:
+    """The trace kernel (trace_helpers.h) replaces two double compares of the reference by float compares:
     '1e-3 <= t' (ray_tracing.cu:22 -> utils.cu:74) and 'fabs(det) < 1e-7' (utils.cu:60).
     Valid because the binary32 nearest to each constant lies ABOVE it and t/det are binary32."""
     f = np.float32
@@ -40,7 +40,7 @@ def test_float_thresholds_used_by_the_kernel():
 
 
 def test_rejection_threshold():
-    """kernels.hip decides the rejection loop `sqrtf(s) > 1` (lambertian.cu:25-26) as
+    """The trace kernel (trace_helpers.h) decides the rejection loop `sqrtf(s) > 1` (lambertian.cu:25-26) as
     `s > 1 + 2^-23`: check the equivalence on every binary32 in a window around 1 and on a
     random sample of the whole range [0, 3]."""
     f = np.float32
