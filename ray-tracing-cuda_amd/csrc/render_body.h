@@ -208,6 +208,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       continue;  // lanes held back from the sparse head of the queue: it has just moved on
     }
 
+#if defined(RTMI_STATS) && RTMI_STATS == 9
+    // (lite build: when this wave has done 600, 1200, ... 5400 queries -> columns 1..9 of its record)
+    if ((wave_queries + 1u) % 600u == 0u && (wave_queries + 1u) / 600u <= 9u && (threadIdx.x & 63u) == 0u)
+      g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][(wave_queries + 1u) / 600u] = stat_real() - t_begin;
+#endif
     RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
               const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
     Hit h = {};
@@ -461,7 +466,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       g_wave_stats[wid][9] = 0, g_wave_stats[wid][10] = 0;
     } else if (wid < 16384u) {
       g_wave_stats[wid][0] = life;
+#if RTMI_STATS != 9
       for (int i = 0; i < 9; i++) g_wave_stats[wid][1 + i] = st.cyc[i];
+#endif
       g_wave_stats[wid][10] = wave_queries, g_wave_stats[wid][11] = st.node_steps, g_wave_stats[wid][12] = st.face_steps;
       g_wave_stats[wid][13] = st.nodes_popped, g_wave_stats[wid][14] = st.insert_rounds;
       g_wave_stats[wid][15] = (st.cyc[9] << 32) | (st.cyc[10] >> 8);  // setup cycles | loop-control cycles / 256

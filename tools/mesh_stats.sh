@@ -44,6 +44,13 @@ if hasattr(L, "rtmi_debug_wave_stats"):
     setup = (ws[:, 15] >> np.uint64(32)).astype(np.float64); ctrl = (ws[:, 15] & np.uint64(0xffffffff)).astype(np.float64) * 256
     ws = ws.astype(np.float64)
     order = np.argsort(-ws[:, 0])
+    if os.environ.get("RTMI_STATS_MARKS"):
+        print("time (Mcyc) at 600, 1200, ... 5400 queries of the longest-lived waves, and cycles per query in between:")
+        for w in order[:6].tolist():
+            r = ws[w]
+            marks = [r[1 + i] for i in range(9) if r[1 + i] > 0]
+            rates = [(b2 - a2) / 600.0 for a2, b2 in zip([0.0] + marks[:-1], marks)]
+            print("  life %6.1f queries %5d | " % (r[0] / 1e6, r[10]) + " ".join("%5.1f" % (m / 1e6) for m in marks) + " | " + " ".join("%5.1fk" % (x / 1e3) for x in rates))
     lifes = np.sort(ws[:, 0])
     print("wave life percentiles (Mcyc): " + "  ".join("p%d %.0f" % (q, np.percentile(lifes, q) / 1e6) for q in (1, 10, 25, 50, 75, 90, 99, 100)))
     for lo, hi in ((0, 10), (10, 25), (25, 50), (50, 75), (75, 90), (90, 100)):
