@@ -17,7 +17,8 @@ from rtmi import scenes
 spp = int(sys.argv[1])
 b = rtmi.SceneBuilder(10086); scenes.bunny(b, 1.0, scenes.procedural_bunny_mesh()); b.commit()
 R = rtmi.Renderer(b, 1024, 1024, spp, 10).init_rng()
-R.render(); torch.cuda.synchronize()
+bpc = int(os.environ.get("RTMI_TOOL_BPC", "0"))
+R.render(opts=rtmi.render_opts(blocks_per_cu=bpc) if bpc else None); torch.cuda.synchronize()
 out = (C.c_ulonglong * 32)()
 rtmi.lib().rtmi_debug_counters(b.h, out, None)
 names = ["queue", "rays", "abandoned", "-", "wave_queries", "searches", "node_steps", "face_steps", "nodes_popped",
