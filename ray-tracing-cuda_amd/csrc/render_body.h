@@ -211,7 +211,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 #if defined(RTMI_STATS) && RTMI_STATS == 9
     // (lite build: when this wave has done 600, 1200, ... 5400 queries -> columns 1..9 of its record)
     if ((wave_queries + 1u) % 600u == 0u && (wave_queries + 1u) / 600u <= 9u && (threadIdx.x & 63u) == 0u)
-      g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][(wave_queries + 1u) / 600u] = stat_real() - t_begin;
+      g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][(wave_queries + 1u) / 600u] =
+          ((stat_real() - t_begin) & 0xffffffffffull) | ((unsigned long long)(st.node_steps + st.face_steps) << 40);
 #endif
     RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
               const unsigned long long in0 = st.cyc[2] + st.cyc[3];)

@@ -43,13 +43,17 @@ if hasattr(L, "rtmi_debug_wave_stats"):
     L.rtmi_debug_wave_stats(ws.ctypes.data_as(C.c_void_p), C.c_size_t(ws.nbytes))
     ws = ws[ws[:, 0] > 0]
     setup = (ws[:, 15] >> np.uint64(32)).astype(np.float64); ctrl = (ws[:, 15] & np.uint64(0xffffffff)).astype(np.float64) * 256
+    ws_raw = ws.copy()
     ws = ws.astype(np.float64)
     order = np.argsort(-ws[:, 0])
     if os.environ.get("RTMI_STATS_MARKS"):
         print("time (Mcyc) at 600, 1200, ... 5400 queries of the longest-lived waves, and cycles per query in between:")
         for w in order[:6].tolist():
             r = ws[w]
-            marks = [r[1 + i] for i in range(9) if r[1 + i] > 0]
+            raw = [int(ws_raw[w][1 + i]) for i in range(9) if ws_raw[w][1 + i] > 0]
+            marks = [float(x & 0xffffffffff) for x in raw]
+            steps = [x >> 40 for x in raw]
+            print("    search steps per query in those spans: " + " ".join("%5.1f" % ((b2 - a2) / 600.0) for a2, b2 in zip([0] + steps[:-1], steps)))
             rates = [(b2 - a2) / 600.0 for a2, b2 in zip([0.0] + marks[:-1], marks)]
             print("  life %6.1f queries %5d | " % (r[0] / 1e6, r[10]) + " ".join("%5.1f" % (m / 1e6) for m in marks) + " | " + " ".join("%5.1fk" % (x / 1e3) for x in rates))
     lifes = np.sort(ws[:, 0])
