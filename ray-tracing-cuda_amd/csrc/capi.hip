@@ -509,7 +509,7 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 // ------------------------------------------------------------------ render
 static size_t scratch_bytes_of(const FrameDev &d) {
   const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-  return n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 64;
+  return n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 64 + (size_t)kHeadCap * 4;
 }
 size_t rtmi_render_scratch_bytes(const rtmi_frame *f) {
   FrameDev d;
@@ -617,9 +617,14 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, SchedPlan(), true, blocks,
                           threads, tune, st));
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
-    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, sparse_cap, tune.outlier_x10, st));
+    static const bool head_classes = env_int("RTMI_HEAD_CLASSES", 1) != 0;
+    uint32_t *p_head = (variant & F_BVH) && head_classes ? p_meta + 16 : nullptr;
+    HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, p_head, sparse_cap, blocks * (threads / 64),
+                              tune.outlier_x10, st));
     plan.tile_order = p_order;
     plan.sparse_items = p_meta + 1;
+    plan.head_list = p_head;
+    plan.probe_marks = p_head ? p_rays : nullptr;
   }
   HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,

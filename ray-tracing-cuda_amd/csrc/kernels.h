@@ -35,6 +35,9 @@ struct RenderTuning {
 struct SchedPlan {
   const uint32_t *tile_order = nullptr;    // local tiles, most expensive first
   const uint32_t *sparse_items = nullptr;  // one word: leading work items handed to every sparse_stride-th lane only
+                                           // (with head_list: + [1], [2] = ends of its 64- and 32-lane classes)
+  const uint32_t *head_list = nullptr;     // optional: the head's work items, heaviest pixels first (kHeadCap words)
+  const uint32_t *probe_marks = nullptr;   // with head_list: per work item, bit 31 set = listed in the head
 };
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan, bool probe,
@@ -42,8 +45,13 @@ hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &f
 // Tiles sorted by descending cost (sum of 64 ray counts each); d_cost/d_order hold n_tiles words,
 // d_meta 16: [0] the largest tile cost, [1] the sparse item count.
 // sparse_cap: work items the grid holds at one pixel per tune.sparse_stride lanes (a multiple of 64).
-hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
-                             uint32_t *d_order, uint32_t sparse_cap, int outlier_x10, hipStream_t stream);
+// d_head (nullable, kHeadCap words): the head's work items sorted into three classes by their own probe count --
+// pixels that get a wave each, pixels that share one between two, the rest (one per 16 lanes); d_meta[2], [3] =
+// where the first two classes end.  grid_waves: waves of the render launch (the classes may use a quarter of them).
+constexpr int kHeadCap = 16384;
+hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
+                             uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
+                             hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);

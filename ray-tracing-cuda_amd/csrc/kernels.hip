@@ -237,14 +237,71 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
   }
 }
 
-hipError_t launch_tile_order(const uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
-                             uint32_t *d_order, uint32_t sparse_cap, int outlier_x10, hipStream_t stream) {
+// One workgroup: the head of the queue, pixel by pixel.  A pixel's chain is as long as its ray count, and a
+// wave's query costs about as much per outlier ray it carries (measured: tools/mesh_stats.sh marks); outlier
+// pixels also sit in tiles that are not outliers as tiles, where they would run their first thousand queries in a
+// full wave.  So the head is made of PIXELS, from the whole frame: those whose probe count is >= pct64 % of the
+// frame's largest get a wave each, >= pct32 % two per wave, >= pct16 % one per 16 lanes -- in a frame whose
+// largest count is at least three times the mean, and as long as that takes no more than a quarter of the grid's
+// waves and kHeadCap entries; else first the lightest class goes, then the heaviest pixels share waves two by two,
+// then there is no head.  Listed pixels get bit 31 of their ray_counts word set: the ordinary queue passes them
+// over.  meta[0] = head entries, meta[1], meta[2] = ends of the first two classes.
+__global__ __launch_bounds__(1024) void head_list_kernel(uint32_t *__restrict__ ray_counts, int n_items,
+                                                         uint32_t *__restrict__ meta, uint32_t *__restrict__ head,
+                                                         uint32_t grid_waves, uint32_t pct64, uint32_t pct32, uint32_t pct16) {
+  __shared__ uint32_t cmax, n_cls[3], at[3];
+  __shared__ unsigned long long total;
+  if (threadIdx.x == 0) cmax = 0u, n_cls[0] = n_cls[1] = n_cls[2] = 0u, total = 0ull;
+  __syncthreads();
+  uint32_t m = 0u;
+  unsigned long long part = 0ull;
+  for (int i = threadIdx.x; i < n_items; i += blockDim.x) m = max(m, ray_counts[i]), part += ray_counts[i];
+  atomicMax(&cmax, m);
+  atomicAdd(&total, part);
+  __syncthreads();
+  const bool skewed = (unsigned long long)cmax * (unsigned long long)n_items >= 3ull * total && cmax >= 4u;
+  const uint32_t none = 0xffffffffu;
+  uint32_t t64 = skewed ? (cmax * pct64 + 99u) / 100u : none, t32 = skewed ? (cmax * pct32 + 99u) / 100u : none,
+           t16 = skewed ? (cmax * pct16 + 99u) / 100u : none;
+  for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+    const uint32_t c = ray_counts[i];
+    if (c >= t16) atomicAdd(&n_cls[c >= t64 ? 0 : c >= t32 ? 1 : 2], 1u);
+  }
+  __syncthreads();
+  uint32_t a = n_cls[0], b = n_cls[1], c3 = n_cls[2];  // (the same arithmetic in every thread)
+  auto over = [&]() { return a + (b + 1u) / 2u + (c3 + 3u) / 4u > grid_waves / 4u || a + b + c3 > (uint32_t)kHeadCap; };
+  if (over()) c3 = 0u, t16 = t32;
+  if (over()) b += a, a = 0u, t64 = none;
+  if (over()) b = 0u, t32 = none, t16 = none;
+  __syncthreads();
+  if (threadIdx.x == 0) at[0] = 0u, at[1] = a, at[2] = a + b, meta[0] = a + b + c3, meta[1] = a, meta[2] = a + b;
+  __syncthreads();
+  if (t16 != none)
+    for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
+      const uint32_t c = ray_counts[i];
+      if (c >= t16) {
+        head[atomicAdd(&at[c >= t64 ? 0 : c >= t32 ? 1 : 2], 1u)] = (uint32_t)i;
+        ray_counts[i] = c | 0x80000000u;
+      }
+    }
+}
+
+hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
+                             uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
+                             hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_meta, 0, 16 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
                      d_meta);
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_meta, n_tiles, d_order, d_meta + 1,
                      sparse_cap, (uint32_t)outlier_x10);
+  if (d_head) {
+    static const int p64 = [] { const char *e = getenv("RTMI_T64"); return e && *e ? atoi(e) : 80; }();
+    static const int p32 = [] { const char *e = getenv("RTMI_T32"); return e && *e ? atoi(e) : 55; }();
+    static const int p16 = [] { const char *e = getenv("RTMI_T16"); return e && *e ? atoi(e) : 30; }();
+    hipLaunchKernelGGL(head_list_kernel, dim3(1), dim3(1024), 0, stream, d_ray_counts, n_tiles * 64, d_meta + 1, d_head,
+                       (uint32_t)grid_waves, (uint32_t)p64, (uint32_t)p32, (uint32_t)p16);
+  }
   return hipGetLastError();
 }
 
@@ -343,6 +400,8 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
   lc.tile_order = plan.tile_order;
   lc.sparse_items = plan.sparse_items;
+  lc.head_list = plan.head_list;
+  lc.probe_marks = plan.probe_marks;
   lc.sparse_stride = tune.sparse_stride;
   lc.exclusive = tune.exclusive;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)

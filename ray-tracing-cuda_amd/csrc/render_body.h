@@ -22,6 +22,8 @@ struct LaunchCfg {
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
   int32_t pad2[1];
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
+  const uint32_t *head_list;     // optional (with sparse_items): the head's items by weight class (SchedPlan::head_list)
+  const uint32_t *probe_marks;   // with head_list: bit 31 of an item's word = it is in the head
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
 };
@@ -106,6 +108,16 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // with full waves.
   unsigned long long sparse_limit = 0ull;
   if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
+  // With a head list (scheduler: head_list_kernel) the head's pixels come in three weight classes: one per
+  // wave (taken by lane 0), one per 32 lanes (lanes 0, 32), one per 16 lanes.  `cls` = the class of the pixel
+  // a lane holds (64 / 32 / 16, 1 for an ordinary pixel); a wave that holds a pixel of class S lets only lanes
+  // that are multiples of S take new pixels.  The head has its own queue (counters[3]); the ordinary queue
+  // (counters[0]) starts behind it.
+  const bool classes = (F & F_BVH) && lc.head_list != nullptr && sparse_limit != 0ull;
+  uint32_t end64 = 0u, end32 = 0u;
+  if (classes) end64 = lc.sparse_items[1], end32 = lc.sparse_items[2];
+  int cls = 1;
+  bool head_open = classes;  // (wave-uniform) the head queue may still hold items
   auto take_item = [&](int64_t item) -> bool {  // false: ragged-tile padding (or nothing to sample), written as black
     q = item;
     int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
@@ -155,7 +167,55 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     }
     const bool wave_heavy = (F & F_BVH) && lc.exclusive &&
                             __builtin_amdgcn_ballot_w64(has_px && heavy && (active || k < fr.spp)) != 0ull;
-    if (!active && !done) {
+    if ((F & F_BVH) && classes) {
+      const bool wants = !active && !done && !has_px;
+      if (__builtin_amdgcn_ballot_w64(wants) != 0ull) {
+        if (head_open)
+          head_open = __hip_atomic_load(&counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < sparse_limit;
+        const uint32_t lane = threadIdx.x & 63u;
+        // four rounds, the lanes that can hold the heavier classes first; the wave's class is looked at again
+        // before each round
+        for (int round = 0; round < 4; round++) {
+          const int lvl = round == 0 ? 64 : round == 1 ? 32 : round == 2 ? 16 : 1;
+          const bool live_px = has_px && (active || k < fr.spp);
+          int wave_cls = 1;
+          if (lc.exclusive) {
+            if (__builtin_amdgcn_ballot_w64(live_px && cls == 16) != 0ull) wave_cls = 16;
+            if (__builtin_amdgcn_ballot_w64(live_px && cls == 32) != 0ull) wave_cls = 32;
+            if (__builtin_amdgcn_ballot_w64(live_px && cls == 64) != 0ull) wave_cls = 64;
+          }
+          if (wave_cls > lvl) break;  // no lane of this or a later round is a multiple of the wave's class
+          const bool my_round = round == 0 ? lane == 0u : round == 1 ? lane == 32u : round == 2 ? (lane & 31u) == 16u
+                                                                                                 : (lane & 15u) != 0u;
+          if (!(wants && my_round)) continue;
+          while (!has_px && !done) {
+            // the head first (its front is the heaviest class left; a lane of level lvl may take classes <= lvl)
+            if (head_open) {
+              const unsigned long long front = __hip_atomic_load(&counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const int front_cls = front < end64 ? 64 : front < end32 ? 32 : 16;
+              if (front < sparse_limit && front_cls <= lvl) {
+                const unsigned long long hq = atomicAdd(&counters[3], 1ull);
+                if (hq < sparse_limit) {
+                  if (take_item((int64_t)lc.head_list[hq])) cls = hq < end64 ? 64 : hq < end32 ? 32 : 16;
+                  continue;
+                }
+              } else if (front < sparse_limit) {
+                break;  // the head's front is for better-aligned lanes: look again next iteration
+              }
+            }
+            const unsigned long long mq = atomicAdd(&counters[0], 1ull);
+            if ((int64_t)mq >= n_items) {
+              // nothing ordinary left: finished once the head is empty too
+              if (__hip_atomic_load(&counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= sparse_limit) done = true;
+              break;
+            }
+            const int64_t item = (int64_t)lc.tile_order[mq >> 6] * 64 + (int64_t)(mq & 63);
+            if (lc.probe_marks[item] >> 31) continue;  // a head item: not from this queue
+            if (take_item(item)) cls = 1;
+          }
+        }
+      }
+    } else if (!active && !done) {
       while (!has_px && !done) {
         if ((F & F_BVH) && sparse_limit != 0ull && (threadIdx.x & (uint32_t)(lc.sparse_stride - 1)) != 0) {
           if (wave_heavy) break;  // this wave is busy with an outlier pixel: stay a helper
@@ -174,6 +234,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         if (!take_item(item)) continue;
         heavy = nq < sparse_limit;
       }
+    }
+    if (!active && !done) {
       if (has_px) {
         // ray_tracing.cu:68-74 + camera.cu:57-70
         float r1 = rng_01(rng);
