@@ -225,11 +225,16 @@ typedef struct rtmi_render_opts {
                               * tail); 2 = always longest-first */
   int32_t blocks_per_cu;     /* 0 default (as many workgroups per CU as fit) */
   int32_t threads_per_block; /* 0 default; a multiple of 64, at most 512 (256 for scenes without meshes) */
-  int32_t sparse_stride;     /* 0 default (16); mesh frames: the outlier tiles at the head of the longest-first
-                              * queue are taken by every sparse_stride-th lane only (power of two, 1..64) */
-  int32_t exclusive;         /* -1 default (1); 1: a wave holding an outlier pixel takes no other new pixels, its
-                              * remaining lanes only help with that pixel's mesh searches; 0: they render too */
-  int32_t outlier_x10;       /* 0 default (20): a tile is an outlier from this many tenths of the mean tile cost */
+  int32_t sparse_stride;     /* 0 default: mesh frames put their outlier PIXELS (found by the probe, anywhere in the
+                              * frame) at the head of the queue in three weight classes -- a wave each, two per
+                              * wave, one per 16 lanes; > 0 (power of two, 1..64): the outlier TILES instead, taken
+                              * by every sparse_stride-th lane only (the scheme before the classes, kept for
+                              * comparison) */
+  int32_t exclusive;         /* -1 default (1); 1: a wave holding an outlier pixel lets only the lanes its class allows
+                              * take new pixels, the remaining lanes only help with that pixel's mesh searches; 0:
+                              * they render too */
+  int32_t outlier_x10;       /* 0 default (20); with sparse_stride > 0: a tile is an outlier from this many tenths of
+                              * the mean tile cost */
   int32_t reserved;
   void *d_scratch;           /* optional device scratch of the longest-first scheduler, owned by the caller; with it */
   size_t scratch_bytes;      /* concurrent renders of one scene on several streams share no state.  NULL: the
@@ -243,8 +248,8 @@ int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_o
 
 /* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
- * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 environment variables override the built-in defaults of those three
- * fields and are read once, when the library is first used. */
+ * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) environment variables override the built-in
+ * defaults of those fields and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);
 

@@ -617,8 +617,11 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, SchedPlan(), true, blocks,
                           threads, tune, st));
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
+    // the head of a mesh frame's queue: pixels in weight classes (the default), or -- when the call names a
+    // sparse stride, or RTMI_HEAD_CLASSES=0 -- the outlier tiles at one pixel per that many lanes
     static const bool head_classes = env_int("RTMI_HEAD_CLASSES", 1) != 0;
-    uint32_t *p_head = (variant & F_BVH) && head_classes ? p_meta + 16 : nullptr;
+    const bool by_pixels = head_classes && !(opts && opts->sparse_stride > 0);
+    uint32_t *p_head = (variant & F_BVH) && by_pixels ? p_meta + 16 : nullptr;
     HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, p_head, sparse_cap, blocks * (threads / 64),
                               tune.outlier_x10, st));
     plan.tile_order = p_order;
