@@ -509,7 +509,7 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 // ------------------------------------------------------------------ render
 static size_t scratch_bytes_of(const FrameDev &d) {
   const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-  return n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 64 + (size_t)kHeadCap * 4;
+  return n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4;
 }
 size_t rtmi_render_scratch_bytes(const rtmi_frame *f) {
   FrameDev d;
@@ -608,7 +608,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_rays = p_states + n * RTMI_STATE_WORDS;
     uint32_t *p_cost = p_rays + n;
     uint32_t *p_order = p_cost + nt;
-    uint32_t *p_meta = p_order + nt;  // 16 words (launch_tile_order)
+    uint32_t *p_meta = p_order + nt;  // 16 + 16 words (launch_tile_order); 450 * nt words in: 8-byte aligned
     HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
     probe.spp = probe_spp;
@@ -621,7 +621,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     // sparse stride, or RTMI_HEAD_CLASSES=0 -- the outlier tiles at one pixel per that many lanes
     static const bool head_classes = env_int("RTMI_HEAD_CLASSES", 1) != 0;
     const bool by_pixels = head_classes && !(opts && opts->sparse_stride > 0);
-    uint32_t *p_head = (variant & F_BVH) && by_pixels ? p_meta + 16 : nullptr;
+    uint32_t *p_head = (variant & F_BVH) && by_pixels ? p_meta + 32 : nullptr;
     HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, p_head, sparse_cap, blocks * (threads / 64),
                               tune.outlier_x10, st));
     plan.tile_order = p_order;

@@ -246,50 +246,73 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t *__rest
 // waves and kHeadCap entries; else first the lightest class goes, then the heaviest pixels share waves two by two,
 // then there is no head.  Listed pixels get bit 31 of their ray_counts word set: the ordinary queue passes them
 // over.  meta[0] = head entries, meta[1], meta[2] = ends of the first two classes.
-__global__ __launch_bounds__(1024) void head_list_kernel(uint32_t *__restrict__ ray_counts, int n_items,
-                                                         uint32_t *__restrict__ meta, uint32_t *__restrict__ head,
-                                                         uint32_t grid_waves, uint32_t pct64, uint32_t pct32, uint32_t pct16) {
-  __shared__ uint32_t cmax, n_cls[3], at[3];
-  __shared__ unsigned long long total;
-  if (threadIdx.x == 0) cmax = 0u, n_cls[0] = n_cls[1] = n_cls[2] = 0u, total = 0ull;
-  __syncthreads();
+// (four small launches over the whole frame instead of one workgroup walking it three times: 0.6 ms -> tens of us)
+// ws[0] largest count, ws[2..3] sum (64 bit), ws[4..6] class counts, ws[8..10] thresholds, ws[12..14] scatter cursors
+__global__ __launch_bounds__(256) void head_scan_kernel(const uint32_t *__restrict__ ray_counts, int n_items,
+                                                        uint32_t *__restrict__ ws) {
   uint32_t m = 0u;
   unsigned long long part = 0ull;
-  for (int i = threadIdx.x; i < n_items; i += blockDim.x) m = max(m, ray_counts[i]), part += ray_counts[i];
-  atomicMax(&cmax, m);
-  atomicAdd(&total, part);
-  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x)
+    m = max(m, ray_counts[i]), part += ray_counts[i];
+  for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, off)), part += __shfl_down(part, off);
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(&ws[0], m);
+    atomicAdd(reinterpret_cast<unsigned long long *>(ws + 2), part);  // (d_meta is 8-byte aligned: capi.hip)
+  }
+}
+__global__ __launch_bounds__(256) void head_count_kernel(const uint32_t *__restrict__ ray_counts, int n_items,
+                                                         uint32_t *__restrict__ ws, uint32_t pct64, uint32_t pct32,
+                                                         uint32_t pct16) {
+  const uint32_t cmax = ws[0];
+  const unsigned long long total = *reinterpret_cast<const unsigned long long *>(ws + 2);
   const bool skewed = (unsigned long long)cmax * (unsigned long long)n_items >= 3ull * total && cmax >= 4u;
-  const uint32_t none = 0xffffffffu;
+  if (!skewed) return;
+  const uint32_t t64 = (cmax * pct64 + 99u) / 100u, t32 = (cmax * pct32 + 99u) / 100u, t16 = (cmax * pct16 + 99u) / 100u;
+  uint32_t c0 = 0u, c1 = 0u, c2 = 0u;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+    const uint32_t c = ray_counts[i];
+    if (c >= t16) (c >= t64 ? c0 : c >= t32 ? c1 : c2)++;
+  }
+  for (int off = 32; off > 0; off >>= 1) c0 += __shfl_down(c0, off), c1 += __shfl_down(c1, off), c2 += __shfl_down(c2, off);
+  if ((threadIdx.x & 63) == 0) {
+    if (c0) atomicAdd(&ws[4], c0);
+    if (c1) atomicAdd(&ws[5], c1);
+    if (c2) atomicAdd(&ws[6], c2);
+  }
+}
+__global__ void head_plan_kernel(int n_items, uint32_t *__restrict__ meta, uint32_t *__restrict__ ws, uint32_t grid_waves,
+                                 uint32_t pct64, uint32_t pct32, uint32_t pct16) {
+  const uint32_t cmax = ws[0], none = 0xffffffffu;
+  const unsigned long long total = *reinterpret_cast<const unsigned long long *>(ws + 2);
+  const bool skewed = (unsigned long long)cmax * (unsigned long long)n_items >= 3ull * total && cmax >= 4u;
   uint32_t t64 = skewed ? (cmax * pct64 + 99u) / 100u : none, t32 = skewed ? (cmax * pct32 + 99u) / 100u : none,
            t16 = skewed ? (cmax * pct16 + 99u) / 100u : none;
-  for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
-    const uint32_t c = ray_counts[i];
-    if (c >= t16) atomicAdd(&n_cls[c >= t64 ? 0 : c >= t32 ? 1 : 2], 1u);
-  }
-  __syncthreads();
-  uint32_t a = n_cls[0], b = n_cls[1], c3 = n_cls[2];  // (the same arithmetic in every thread)
+  uint32_t a = ws[4], b = ws[5], c3 = ws[6];
   auto over = [&]() { return a + (b + 1u) / 2u + (c3 + 3u) / 4u > grid_waves / 4u || a + b + c3 > (uint32_t)kHeadCap; };
   if (over()) c3 = 0u, t16 = t32;
   if (over()) b += a, a = 0u, t64 = none;
   if (over()) b = 0u, t32 = none, t16 = none;
-  __syncthreads();
-  if (threadIdx.x == 0) at[0] = 0u, at[1] = a, at[2] = a + b, meta[0] = a + b + c3, meta[1] = a, meta[2] = a + b;
-  __syncthreads();
-  if (t16 != none)
-    for (int i = threadIdx.x; i < n_items; i += blockDim.x) {
-      const uint32_t c = ray_counts[i];
-      if (c >= t16) {
-        head[atomicAdd(&at[c >= t64 ? 0 : c >= t32 ? 1 : 2], 1u)] = (uint32_t)i;
-        ray_counts[i] = c | 0x80000000u;
-      }
+  meta[0] = a + b + c3, meta[1] = a, meta[2] = a + b;
+  ws[8] = t64, ws[9] = t32, ws[10] = t16;
+  ws[12] = 0u, ws[13] = a, ws[14] = a + b;  // scatter cursors
+}
+__global__ __launch_bounds__(256) void head_scatter_kernel(uint32_t *__restrict__ ray_counts, int n_items,
+                                                           uint32_t *__restrict__ head, uint32_t *__restrict__ ws) {
+  const uint32_t t64 = ws[8], t32 = ws[9], t16 = ws[10];
+  if (t16 == 0xffffffffu) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+    const uint32_t c = ray_counts[i];
+    if (c >= t16) {
+      head[atomicAdd(&ws[12 + (c >= t64 ? 0 : c >= t32 ? 1 : 2)], 1u)] = (uint32_t)i;
+      ray_counts[i] = c | 0x80000000u;
     }
+  }
 }
 
 hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
                              hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(d_meta, 0, 16 * sizeof(uint32_t), stream);
+  hipError_t e = hipMemsetAsync(d_meta, 0, 32 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
                      d_meta);
@@ -299,8 +322,14 @@ hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_co
     static const int p64 = [] { const char *e = getenv("RTMI_T64"); return e && *e ? atoi(e) : 80; }();
     static const int p32 = [] { const char *e = getenv("RTMI_T32"); return e && *e ? atoi(e) : 55; }();
     static const int p16 = [] { const char *e = getenv("RTMI_T16"); return e && *e ? atoi(e) : 30; }();
-    hipLaunchKernelGGL(head_list_kernel, dim3(1), dim3(1024), 0, stream, d_ray_counts, n_tiles * 64, d_meta + 1, d_head,
-                       (uint32_t)grid_waves, (uint32_t)p64, (uint32_t)p32, (uint32_t)p16);
+    uint32_t *ws = d_meta + 16;  // 16 words of workspace behind the 16 of d_meta (zeroed with them)
+    const int n_items = n_tiles * 64, blocks = n_items / 4096 > 0 ? (n_items / 4096 < 1024 ? n_items / 4096 : 1024) : 1;
+    hipLaunchKernelGGL(head_scan_kernel, dim3(blocks), dim3(256), 0, stream, d_ray_counts, n_items, ws);
+    hipLaunchKernelGGL(head_count_kernel, dim3(blocks), dim3(256), 0, stream, d_ray_counts, n_items, ws, (uint32_t)p64,
+                       (uint32_t)p32, (uint32_t)p16);
+    hipLaunchKernelGGL(head_plan_kernel, dim3(1), dim3(1), 0, stream, n_items, d_meta + 1, ws, (uint32_t)grid_waves,
+                       (uint32_t)p64, (uint32_t)p32, (uint32_t)p16);
+    hipLaunchKernelGGL(head_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_ray_counts, n_items, d_head, ws);
   }
   return hipGetLastError();
 }
