@@ -108,7 +108,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // with full waves.
   unsigned long long sparse_limit = 0ull;
   if ((F & F_BVH) && lc.sparse_items) sparse_limit = *lc.sparse_items;
-  // With a head list (scheduler: head_list_kernel) the head's pixels come in three weight classes: one per
+  // With a head list (scheduler: head_scan / count / plan / scatter kernels) the head's pixels come in three weight classes: one per
   // wave (taken by lane 0), one per 32 lanes (lanes 0, 32), one per 16 lanes.  `cls` = the class of the pixel
   // a lane holds (64 / 32 / 16, 1 for an ordinary pixel); a wave that holds a pixel of class S lets only lanes
   // that are multiples of S take new pixels.  The head has its own queue (counters[3]); the ordinary queue
