@@ -249,7 +249,8 @@ int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_o
 /* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
  * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) environment variables override the built-in
- * defaults of those fields and are read once, when the library is first used. */
+ * defaults of those fields (and RTMI_T64 / RTMI_T32 / RTMI_T16, per cent of the frame's largest probe count, the three
+ * weight classes' thresholds: 80 / 55 / 30) and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);
 
