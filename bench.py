@@ -10,7 +10,11 @@ Workloads (BASELINE.json ``configs``; scene constants are the reference's InitWo
   c3  scenes/bunny (stand-in mesh) 1024x1024 x512 spp d10   — reported under config.extra at N=1
   c4  scenes/cornell_box 2048x2048 x4096 spp depth 50       — the N>1 line: FIXED frame, strong scaling
   c5  scenes/birthday 4096x4096 x8192 spp depth 10
-``--workload auto`` (default) picks c2 for N=1 and c4 for N>1.
+  c1  scenes/spheres 256x256 x16 spp depth 8 (configs[0]) and c1big, the same scene at 1024x1024 x64 spp
+``--workload auto`` (default) picks c2 for N=1 and c4 for N>1.  ``--shard r/G`` renders shard r of a G-rank frame
+on this one GPU (what rank r of G would render); ``--shard-sweep G`` renders the full frame and then each of the G
+shards of the workload in turn and reports ``predicted_speedup = T(full frame) / max_r T(shard r)`` -- the
+strong-scaling figure a G-GPU node can reach at best, measured on one GPU.
 
 Launch: ``python bench.py --gpus N`` starts its own N ranks (one process per GPU, before any
 GPU call in the parent) unless it already runs under ``python -m torch.distributed.run``
@@ -43,6 +47,8 @@ WORKLOADS = {
     "c3": dict(scene="bunny", size=1024, spp=512, depth=10),
     "c4": dict(scene="cornell_box", size=2048, spp=4096, depth=50),
     "c5": dict(scene="birthday", size=4096, spp=8192, depth=10),
+    "c1": dict(scene="spheres", size=256, spp=16, depth=8),
+    "c1big": dict(scene="spheres", size=1024, spp=64, depth=8),
 }
 
 
@@ -57,7 +63,11 @@ def parse(argv=None):
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the config.extra C3 line")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config.extra lines (C3, C1, C4 / C5 shard 0 of 8)")
+    ap.add_argument("--shard", default=None, help="r/G: render shard r of a G-rank frame on this one GPU")
+    ap.add_argument("--shard-sweep", type=int, default=0, metavar="G",
+                    help="full frame, then each of the G shards, on this one GPU: predicted G-GPU speedup")
+    ap.add_argument("--priority", type=int, default=-1, help="rtmi_render_opts.priority (-1: library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--selftest-exchange", action="store_true",
@@ -114,34 +124,42 @@ def host_cores():
     return n
 
 
-def cpu_baseline():
-    """The oracle (CPU restatement, kind "port") on SURVEY 8(d)'s two samples: C1 = spheres
-    256x256 x16 spp depth 8 (configs[0]) and a reduced C2 = cornell_box 256x256 x64 spp depth 50.
-    RNG seeding is outside the timed region, as the reference's kernel-only timing is
-    (utils.cu:155-170).  ``value`` is the reduced-C2 rate (the scene of the N=1 line)."""
+def cpu_baseline(target_s=6.0):
+    """The oracle (CPU restatement, kind "port") on SURVEY 8(d)'s two scenes: C1 = spheres 256x256 depth 8
+    (configs[0]) and a reduced C2 = cornell_box 256x256 depth 50.  Each is first timed at SURVEY's sample count
+    (16 / 64 spp: a fraction of a second, thread start-up included), then at as many samples per pixel as make the
+    run last about ``target_s`` seconds -- that second run is what is reported.  RNG seeding is outside the timed
+    region, as the reference's kernel-only timing is (utils.cu:155-170).  ``value`` is the reduced-C2 rate (the
+    scene of the N=1 line)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oraclelib
     from rtmi import scenes
     cores = host_cores()
     res = {}
-    for tag, name, side, spp, depth in (("c1_spheres_256x256x16_d8", "spheres", 256, 16, 8),
-                                        ("c2_reduced_cornell_256x256x64_d50", "cornell_box", 256, 64, 50)):
+    for tag, name, side, spp0, depth in (("c1_spheres_256x256_d8", "spheres", 256, 16, 8),
+                                         ("c2_reduced_cornell_256x256_d50", "cornell_box", 256, 64, 50)):
         seed = scenes.SCENE_SEEDS[name]
         b = build_scene(oraclelib.OracleBuilder(seed), name, 1.0)
-        states = oraclelib.rng_init(seed, side * side)
-        states[0] = b.state0
-        t0 = time.time()
-        _, _, _, rays = b.render(side, side, spp, depth, threads=cores, states=states)
-        dt = time.time() - t0
-        res[tag] = {"mrays_per_s": rays / dt / 1e6, "rays": rays, "seconds": dt,
-                    "mrays_per_s_per_thread": rays / dt / 1e6 / cores}
-    main = res["c2_reduced_cornell_256x256x64_d50"]
+
+        def run(spp):
+            states = oraclelib.rng_init(seed, side * side)
+            states[0] = b.state0
+            t0 = time.time()
+            _, _, _, rays = b.render(side, side, spp, depth, threads=cores, states=states)
+            return rays, time.time() - t0
+
+        rays0, dt0 = run(spp0)
+        spp = int(min(64 * spp0, max(spp0, spp0 * round(target_s / max(dt0, 1e-3)))))
+        rays, dt = run(spp) if spp > spp0 else (rays0, dt0)
+        res[tag] = {"spp": spp, "mrays_per_s": rays / dt / 1e6, "rays": rays, "seconds": dt,
+                    "mrays_per_s_per_thread": rays / dt / 1e6 / cores,
+                    "survey_sample": {"spp": spp0, "rays": rays0, "seconds": dt0, "mrays_per_s": rays0 / dt0 / 1e6}}
+    main, c1 = res["c2_reduced_cornell_256x256_d50"], res["c1_spheres_256x256_d8"]
     return {"value": main["mrays_per_s"], "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "cornell_box 256x256 x64spp depth50: %d rays in %.1fs; spheres 256x256 x16spp depth8: %d rays in "
+            "sample": "cornell_box 256x256 x%dspp depth50: %d rays in %.1fs; spheres 256x256 x%dspp depth8: %d rays in "
                       "%.1fs (oracle, g++ -O2 -ffp-contract=off, %d threads, render loop only)" %
-                      (main["rays"], main["seconds"], res["c1_spheres_256x256x16_d8"]["rays"],
-                       res["c1_spheres_256x256x16_d8"]["seconds"], cores),
-            "samples": res}
+                      (main["spp"], main["rays"], main["seconds"], c1["spp"], c1["rays"], c1["seconds"], cores),
+            "per_thread": main["mrays_per_s_per_thread"], "samples": res}
 
 
 def roofline_inputs():
@@ -151,52 +169,89 @@ def roofline_inputs():
         return {}
 
 
-def roofline(w, rays_rank, kern_ms, bytes_per_ray, n_simd):
-    """VALU-issue roofline of the trace kernel on this rank (see the module docstring)."""
-    inp = roofline_inputs().get("kernels", {}).get(w["scene"])
+def kernel_source_hash():
+    """sha256 over the kernel sources (ray-tracing-cuda_amd/csrc): tools/summarize_profile.py records it with
+    every PMC digest, and a digest taken from other sources than the ones built here is not used."""
+    import hashlib
+    d = os.path.join(ROOT, "ray-tracing-cuda_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode() + b"\0" + open(os.path.join(d, name), "rb").read() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def roofline_key(w, shard=None):
+    key = "%dx%dx%d_d%d" % (w["size"], w["size"], w["spp"], w["depth"])
+    return key + ("_s%dof%d" % shard if shard else "")
+
+
+def roofline(w, rays_rank, kern_ms, bytes_per_ray, n_simd, shard=None):
+    """VALU-issue roofline of the trace kernel on this rank (see the module docstring).  The instruction counts per
+    64 rays come from the committed PMC digest of THIS scene and frame shape; a digest taken from other kernel
+    sources (or none for this shape) leaves ``frac`` null and says why -- the line is printed either way."""
+    digest = roofline_inputs()
+    scene = digest.get("kernels", {}).get(w["scene"], {})
+    key = roofline_key(w, shard)
+    inp = scene.get("shapes", {}).get(key)
     hbm_alg = rays_rank * bytes_per_ray / (kern_ms * 1e-3) / 1e9
     out = {"bound": "valu_issue", "achieved": None, "peak": kern_ms * 1e-3 * CLOCK_GHZ * 1e9, "unit": "cycles/SIMD",
            "frac": None, "traffic": None,
            "hbm": {"algorithmic_gbs": hbm_alg, "peak_gbs": HBM_PEAK_GBS, "algorithmic_frac": hbm_alg / HBM_PEAK_GBS,
                    "note": "SURVEY 8(d) bytes/ray x rays / kernel time; these bytes are served from SGPRs / the "
                            "scalar cache / LDS, not HBM (see traffic)"}}
-    if inp:
-        valu, trans = inp["valu_per_64_rays"], inp["trans_per_64_rays"]
-        cyc = (CYC_VALU * valu + (CYC_TRANS - CYC_VALU) * trans) * (rays_rank / 64.0) / n_simd
-        out.update(achieved=cyc, frac=cyc / out["peak"], valu_per_64_rays=valu, trans_per_64_rays=trans,
-                   clock_ghz=CLOCK_GHZ, n_simd=n_simd, source=inp.get("source"))
-        key = "%dx%dx%d_d%d" % (w["size"], w["size"], w["spp"], w["depth"])
-        tr = inp.get("hbm_bytes_per_launch", {}).get(key)
-        if tr is not None:
-            out["traffic"] = tr
-            out["hbm"]["measured_gbs"] = tr / (kern_ms * 1e-3) / 1e9
-            out["hbm"]["measured_frac"] = tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if out["frac"] > 1.0:
-            raise SystemExit("roofline.frac %.3f > 1: profiles/roofline_inputs.json does not describe the kernel that "
-                             "ran (regenerate it with tools/profile_bench.sh)" % out["frac"])
+    if not inp:
+        out["stale_inputs"] = "no PMC digest for %s %s in profiles/roofline_inputs.json" % (w["scene"], key)
+        return out
+    built, profiled = kernel_source_hash(), digest.get("kernel_source_hash")
+    if profiled != built:
+        out["stale_inputs"] = ("profiles/roofline_inputs.json was taken from kernel sources %s, these are %s: "
+                               "re-run tools/profile_bench.sh" % (profiled, built))
+        sys.stderr.write("bench.py: warning: %s\n" % out["stale_inputs"])
+        return out
+    valu, trans = inp["valu_per_64_rays"], inp["trans_per_64_rays"]
+    cyc = (CYC_VALU * valu + (CYC_TRANS - CYC_VALU) * trans) * (rays_rank / 64.0) / n_simd
+    out.update(achieved=cyc, frac=cyc / out["peak"], valu_per_64_rays=valu, trans_per_64_rays=trans,
+               clock_ghz=CLOCK_GHZ, n_simd=n_simd, source=inp.get("source"), kernel_source_hash=built)
+    tr = inp.get("hbm_bytes_per_launch")
+    if tr is not None:
+        out["traffic"] = tr
+        out["hbm"]["measured_gbs"] = tr / (kern_ms * 1e-3) / 1e9
+        out["hbm"]["measured_frac"] = tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+    if out["frac"] > 1.0:  # cannot be: the counts are not this kernel's after all
+        out["stale_inputs"] = "frac %.3f > 1: the digest does not describe the kernel that ran" % out["frac"]
+        sys.stderr.write("bench.py: warning: %s\n" % out["stale_inputs"])
+        out["achieved"] = out["frac"] = None
     return out
 
 
-def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmup):
+def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmup, shard=None, scene=None):
+    """Time `steps` frames of workload `w`.  shard = (r, G): this one GPU renders what rank r of G would (no
+    exchange); otherwise rank / world are the process group's."""
     from rtmi import scenes
     from rtmi.dist import gather_to_root
     H = W = w["size"]
     seed = scenes.SCENE_SEEDS[w["scene"]]
-    scene = build_scene(rtmi.SceneBuilder(seed), w["scene"], W / H).commit()
+    if scene is None:
+        scene = build_scene(rtmi.SceneBuilder(seed), w["scene"], W / H).commit()
     bytes_per_ray = scene.bytes_per_ray()
-    R = rtmi.Renderer(scene, H, W, w["spp"], w["depth"], True, rank=rank, world_size=world)
+    r_rank, r_world = shard if shard else (rank, world)
+    R = rtmi.Renderer(scene, H, W, w["spp"], w["depth"], True, rank=r_rank, world_size=r_world)
     R.init_rng()
     pristine = R.states.clone()
+    opts = rtmi.render_opts(priority=args.priority) if args.priority >= 0 else None
+    shape = R.launch_shape(opts)
     torch.cuda.synchronize()
 
     def step(ev=None):
         R.states.copy_(pristine)
         if ev:
             ev[0].record()
-        R.render()
+        R.render(opts=opts)
         if ev:
             ev[1].record()
-        if use_dist:
+        if use_dist and not shard:
+            R.check()  # an incomplete frame raises here, before it is handed on
             allt = gather_to_root(R.tiles, 0)
             if rank == 0:
                 R.untile(allt)
@@ -218,11 +273,12 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
     dt = time.perf_counter() - t0
 
     rays_rank = R.total_rays()  # rays of one step on this rank (identical every step)
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, steps)
+    kerns = [a.elapsed_time(b) for a, b in events]
+    kern_ms = sum(kerns) / max(1, steps)
     per_rank_ms = [kern_ms]
     rays_all = float(rays_rank)
     n_seen = 1
-    if use_dist:
+    if use_dist and not shard:
         tt = torch.tensor([dt, float(rays_rank), kern_ms], dtype=torch.float64, device="cuda")
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -234,8 +290,47 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
         per_rank_ms = [float(x[0]) for x in allk]
         n_seen = dist.get_world_size()
     n_simd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * 4
-    return dict(H=H, W=W, seed=seed, dt=dt, rays_rank=rays_rank, rays_all=rays_all, kern_ms=kern_ms,
-                per_rank_ms=per_rank_ms, n_seen=n_seen, bytes_per_ray=bytes_per_ray, n_simd=n_simd)
+    pixels_rank = int((rtmi.pixel_map(R.frame) >= 0).sum())
+    return dict(H=H, W=W, seed=seed, dt=dt, rays_rank=rays_rank, rays_all=rays_all, kern_ms=kern_ms, kern_ms_all=kerns,
+                per_rank_ms=per_rank_ms, n_seen=n_seen, bytes_per_ray=bytes_per_ray, n_simd=n_simd, shape=shape,
+                pixels_rank=pixels_rank, items=R.items, scene=scene)
+
+
+def extra_line(tag, w, r, steps, shard=None):
+    """One config.extra entry: a further BASELINE config (or one shard of it) on this GPU, with its own roofline."""
+    lanes = r["shape"]["blocks"] * r["shape"]["threads"]
+    return {"workload": "%s: scenes/%s %dx%d x%dspp depth%d seed%d%s" %
+                        (tag, w["scene"], r["H"], r["W"], w["spp"], w["depth"], r["seed"],
+                         " -- shard %d of %d (what one GPU of %d renders)" % (shard[0], shard[1], shard[1]) if shard else ""),
+            "value": r["rays_all"] * steps / r["dt"] / 1e6, "unit": "Mrays/s", "ms_per_step": r["dt"] / steps * 1e3,
+            "kernel_ms": r["kern_ms"], "kernel_ms_min_max": [min(r["kern_ms_all"]), max(r["kern_ms_all"])],
+            "rays_per_step": r["rays_all"], "pixels": r["pixels_rank"], "resident_lanes": lanes,
+            "pixels_per_lane": r["pixels_rank"] / float(lanes),
+            "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"], shard)}
+
+
+def shard_sweep(rtmi, torch, w, G, args):
+    """T(full frame on one GPU) against T(each of the G shards on one GPU): rank r of G renders exactly shard r, so
+    max_r T(shard r) (+ the gather, bytes stated) is the G-GPU frame time a node can reach, measured here."""
+    rr = run_workload(rtmi, torch, None, w, args, 0, 1, False, 1, 1)  # warm-up loads the code object
+    full = {"kernel_ms": rr["kern_ms"], "rays": rr["rays_all"], "pixels": rr["pixels_rank"],
+            "resident_lanes": rr["shape"]["blocks"] * rr["shape"]["threads"]}
+    scene = rr["scene"]
+    shards = []
+    for r in range(G):
+        x = run_workload(rtmi, torch, None, w, args, 0, 1, False, 1, 0, shard=(r, G), scene=scene)
+        lanes = x["shape"]["blocks"] * x["shape"]["threads"]
+        shards.append({"shard": r, "kernel_ms": x["kern_ms"], "rays": x["rays_all"], "pixels": x["pixels_rank"],
+                       "resident_lanes": lanes, "pixels_per_lane": x["pixels_rank"] / float(lanes),
+                       "mrays_per_s": x["rays_all"] / x["kern_ms"] / 1e3,
+                       "gather_bytes": x["items"] * 12})
+    worst = max(s_["kernel_ms"] for s_ in shards)
+    return {"workload": "%s: scenes/%s %dx%d x%dspp depth%d" % (w["name"], w["scene"], w["size"], w["size"], w["spp"], w["depth"]),
+            "G": G, "full_frame": full, "shards": shards, "max_shard_ms": worst,
+            "predicted_speedup": full["kernel_ms"] / worst, "predicted_efficiency": full["kernel_ms"] / worst / G,
+            "ray_total_matches": abs(sum(s_["rays"] for s_ in shards) - full["rays"]) < 0.5,
+            "note": "kernel-only times on ONE GPU; the G-GPU step adds one gather of gather_bytes per rank to rank 0 "
+                    "(direct xGMI links, ~153 GB/s each) and the untile kernel"}
 
 
 def selftest_exchange(args):
@@ -305,38 +400,54 @@ def main():
         rtmi.lib().rtmi_set_launch(args.blocks_per_cu, args.threads)
 
     w = pick_workload(args, world)
-    r = run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, args.steps, args.warmup)
+    if args.shard_sweep:
+        if world != 1:
+            raise SystemExit("--shard-sweep runs on one GPU")
+        print(json.dumps({"shard_sweep": shard_sweep(rtmi, torch, w, args.shard_sweep, args)}), flush=True)
+        return
+    shard = None
+    if args.shard:
+        if world != 1:
+            raise SystemExit("--shard r/G renders one shard on ONE GPU")
+        shard = tuple(int(x) for x in args.shard.split("/"))
+        if len(shard) != 2 or not 0 <= shard[0] < shard[1]:
+            raise SystemExit("--shard wants r/G with 0 <= r < G")
+    r = run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, args.steps, args.warmup, shard=shard)
 
     if rank == 0:
         value = r["rays_all"] * args.steps / r["dt"] / 1e6
+        lanes = r["shape"]["blocks"] * r["shape"]["threads"]
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["dt"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": "%s: scenes/%s %dx%d x%dspp depth%d seed%d (fixed frame; 8x8 tiles interleaved over %d "
-                            "rank(s); step = trace kernel%s)" %
-                            (w["name"], w["scene"], r["H"], r["W"], w["spp"], w["depth"], r["seed"], world,
+                            "rank(s)%s; step = trace kernel%s)" %
+                            (w["name"], w["scene"], r["H"], r["W"], w["spp"], w["depth"], r["seed"],
+                             shard[1] if shard else world, ", shard %d only" % shard[0] if shard else "",
                              " + RCCL gather + untile" if world > 1 else " + untile"),
-                "rays_per_step": r["rays_all"], "msamples_per_s": r["H"] * r["W"] * w["spp"] * args.steps / r["dt"] / 1e6,
+                "rays_per_step": r["rays_all"], "msamples_per_s": (r["pixels_rank"] if shard else r["H"] * r["W"]) * w["spp"] * args.steps / r["dt"] / 1e6,
                 "bytes_per_ray": r["bytes_per_ray"], "kernel_ms": max(r["per_rank_ms"]),
                 "kernel_ms_per_rank": r["per_rank_ms"], "n_ranks_seen": r["n_seen"],
+                "resident_lanes_per_rank": lanes, "pixels_per_lane": r["pixels_rank"] / float(lanes),
             },
-            "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"]),
+            "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"], shard),
         }
-    if world == 1 and not args.no_extra and w["name"] == "c2":
-        # BASELINE configs[2] (mesh + BVH) beside the headline: same contract, shorter run
-        w3 = dict(WORKLOADS["c3"], name="c3")
-        r3 = run_workload(rtmi, torch, dist, w3, args, rank, world, use_dist, max(1, min(args.steps, 5)), 1)
+    if world == 1 and not args.no_extra and w["name"] == "c2" and not shard:
+        # the other BASELINE configs one GPU carries, beside the headline: same contract, shorter runs.
+        # configs[2] (mesh + BVH); configs[0] (spheres) and its 1024x1024 shape; configs[3] / configs[4] as the
+        # shard one GPU of eight renders, at their full sample counts
+        extras = []
+        for tag, wl, sh, n in (("c3", "c3", None, 5), ("c1", "c1", None, 5), ("c1big", "c1big", None, 3),
+                               ("c4", "c4", (0, 8), 2), ("c5", "c5", (0, 8), 1)):
+            wx = dict(WORKLOADS[wl], name=tag)
+            nx = max(1, min(args.steps, n))
+            rx = run_workload(rtmi, torch, dist, wx, args, rank, world, use_dist, nx, 1, shard=sh)
+            if rank == 0:
+                extras.append(extra_line(tag, wx, rx, nx, sh))
         if rank == 0:
-            out["config"]["extra"] = [{
-                "workload": "c3: scenes/bunny (procedural stand-in mesh, 69,312 faces) %dx%d x%dspp depth%d seed%d" %
-                            (r3["H"], r3["W"], w3["spp"], w3["depth"], r3["seed"]),
-                "value": r3["rays_all"] * max(1, min(args.steps, 5)) / r3["dt"] / 1e6, "unit": "Mrays/s",
-                "ms_per_step": r3["dt"] / max(1, min(args.steps, 5)) * 1e3, "kernel_ms": r3["kern_ms"],
-                "rays_per_step": r3["rays_all"],
-                "roofline": roofline(w3, r3["rays_rank"], r3["kern_ms"], r3["bytes_per_ray"], r3["n_simd"]),
-            }]
+            out["config"]["extra"] = extras
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

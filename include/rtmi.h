@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RTMI_VERSION 1
+#define RTMI_VERSION 2
 #define RTMI_TILE 8            /* tile edge in pixels; 64 work items per tile = one wavefront */
 #define RTMI_STATE_WORDS 6     /* live words of curandState: d, v[0..4] */
 
@@ -178,14 +178,22 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
  * Asynchronous on `stream`. */
 int rtmi_render(const rtmi_scene *s, const rtmi_frame *f, void *d_states, float *d_tiles,
                 uint32_t *d_ray_counts, void *stream);
-/* Total closest-hit queries of the most recent rtmi_render on this scene
- * (waits for `stream`).  RTMI_ERR_INTERNAL if that render abandoned a mesh search. */
+/* Did the render complete?  Waits for `stream`, then returns RTMI_OK, or RTMI_ERR_INTERNAL when the render
+ * abandoned a mesh search (the frame is then incomplete and must not be used).  `d_scratch`: the
+ * rtmi_render_opts.d_scratch that call was given, or NULL for a call without one (the most recent such call on
+ * this scene).  out_rays (nullable) receives the call's total of closest-hit queries.  The reference has no
+ * counterpart: its CHECKs abort (utils.cu:164-166). */
+int rtmi_render_status(const rtmi_scene *s, const void *d_scratch, uint64_t *out_rays, void *stream);
+/* rtmi_render_status(s, NULL, out_rays, stream). */
 int rtmi_last_ray_total(const rtmi_scene *s, uint64_t *out_rays, void *stream);
-/* Diagnostic: the library's raw device counter words of the most recent rtmi_render on this scene
- * ([0] work-queue head, [1] closest-hit queries, [2] abandoned mesh searches; a -DRTMI_STATS build
- * of the kernels adds wave-level step counts of the mesh search from word 4 on). */
-#define RTMI_COUNTER_WORDS 32
+/* Diagnostic: the raw device counter words of a render ([0] work-queue head, [1] closest-hit queries,
+ * [2] abandoned mesh searches, [3] head-queue cursor; a -DRTMI_STATS build of the kernels adds wave-level
+ * step counts of the mesh search from word 4 on; a -DRTMI_CHECK_MARGINS build counts, in [33] / [34], the
+ * sampled queries it re-did without the cull and the disagreements it found). */
+#define RTMI_COUNTER_WORDS 40
 int rtmi_debug_counters(const rtmi_scene *s, unsigned long long out[RTMI_COUNTER_WORDS], void *stream);
+int rtmi_debug_counters_ex(const rtmi_scene *s, const void *d_scratch, unsigned long long out[RTMI_COUNTER_WORDS],
+                           void *stream);
 
 /* d_all_tiles holds the tile-major buffers of ranks 0..world_size-1 back to
  * back (what an RCCL gather to the root produces; world_size==1: the buffer
@@ -194,6 +202,18 @@ int rtmi_debug_counters(const rtmi_scene *s, unsigned long long out[RTMI_COUNTER
 int rtmi_untile(const rtmi_frame *f, const float *d_all_tiles, float *d_image, void *stream);
 /* Same for per-pixel ray counts. */
 int rtmi_untile_u32(const rtmi_frame *f, const uint32_t *d_all_counts, uint32_t *d_image_counts, void *stream);
+
+/* The N > 1 exchange, on caller-owned buffers and a caller-owned RCCL communicator (an ncclComm_t passed as
+ * void*, rank == frame->rank, size == frame->world_size).  Replaces GatherImageData's MPI_Reduce of full frames on
+ * host memory (utils.cu:115-130, 232-238): every rank sends its float[work_items][3] tile buffer to `root` over its
+ * direct xGMI link (grouped ncclSend / ncclRecv), the root's d_all_tiles (world_size buffers back to back, what
+ * rtmi_untile takes) also receives its own.  world_size 1: a device copy, comm may be NULL.  Asynchronous on
+ * `stream`.  RCCL is looked up in the process at run time; librtmi.so does not link against it. */
+int rtmi_gather(void *nccl_comm, const rtmi_frame *f, const float *d_tiles, float *d_all_tiles, int root, void *stream);
+/* The reference's own decomposition (every rank renders the whole frame with GetWorkload's share of the samples,
+ * post_process = 0): ncclReduce(sum) of the tile buffers into `root`, in place; follow with rtmi_untile and
+ * rtmi_post_process.  comm NULL = one rank. */
+int rtmi_reduce_sum(void *nccl_comm, const rtmi_frame *f, float *d_tiles, int root, void *stream);
 
 /* GatherImageData's root-side step on a summed image (utils.cu:126-129):
  * rgb = sqrt(clamp(rgb / spp, 0, 1)), in place over n_pixels*3 floats. */
@@ -235,22 +255,32 @@ typedef struct rtmi_render_opts {
                               * they render too */
   int32_t outlier_x10;       /* 0 default (20); with sparse_stride > 0: a tile is an outlier from this many tenths of
                               * the mean tile cost */
+  int32_t priority;          /* -1 default; 1: a wave's issue priority follows the rank of the tiles it holds in the
+                              * longest-first order (the frame's longest chains run ahead of the bulk); 0: off */
+  int32_t head_pct[3];       /* 0 default (80, 55, 30): mesh frames, per cent of the frame's largest probe count from
+                              * which a pixel gets a wave to itself / shares one with another / gets one lane in 16 */
   int32_t reserved;
-  void *d_scratch;           /* optional device scratch of the longest-first scheduler, owned by the caller; with it */
-  size_t scratch_bytes;      /* concurrent renders of one scene on several streams share no state.  NULL: the
-                              * scene caches one, which ties renders of that scene to one stream at a time. */
+  void *d_scratch;           /* optional device memory for ALL per-call state (work-queue cursors, ray total,
+                              * completion flag, the scheduler's buffers), owned by the caller, at least */
+  size_t scratch_bytes;      /* rtmi_render_scratch_bytes(frame) bytes: with it, concurrent renders of one scene
+                              * (several streams, or N shards on one device) share nothing but the read-only scene,
+                              * and rtmi_render_status(s, d_scratch, ..) reports on exactly that call.  NULL: the
+                              * scene's own, which ties renders of that scene to one at a time. */
 } rtmi_render_opts;
-/* Bytes of d_scratch the scheduler needs for this frame / shard. */
+/* Bytes of d_scratch a render of this frame / shard needs. */
 size_t rtmi_render_scratch_bytes(const rtmi_frame *f);
+/* The launch a render of this frame would use on the current device: {workgroups, lanes per workgroup,
+ * workgroups per compute unit, compute units}.  workgroups x lanes = the lanes resident at once, each of which
+ * holds one pixel at a time (utils.cu:158 fixes dim3(8,8) blocks over the whole frame instead). */
+int rtmi_render_launch_shape(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[4]);
 /* rtmi_render with per-call options (opts == NULL: the defaults). */
 int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
                    float *d_tiles, uint32_t *d_ray_counts, void *stream);
 
 /* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
- * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) environment variables override the built-in
- * defaults of those fields (and RTMI_T64 / RTMI_T32 / RTMI_T16, per cent of the frame's largest probe count, the three
- * weight classes' thresholds: 80 / 55 / 30) and are read once, when the library is first used. */
+ * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PRIORITY environment variables override the
+ * built-in defaults of those fields and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);
 

@@ -495,26 +495,7 @@ static void rt_comm_init(RtComm *c) {
   if (c->rank == 0) std::remove(path.c_str());  // every rank holds the id once the communicator exists
 }
 
-// Gather `count` floats from every rank into rank 0's buffer (rank r at offset r*count).
-static void rt_gather(RtComm *c, const float *d_send, float *d_recv_root, size_t count, hipStream_t stream) {
-  if (c->world <= 1) return;
-  CHECK(ncclGroupStart() == ncclSuccess);
-  if (c->rank == 0) {
-    for (int r = 1; r < c->world; r++)
-      CHECK(ncclRecv(d_recv_root + (size_t)r * count, count, ncclFloat, r, c->comm, stream) == ncclSuccess);
-  } else {
-    CHECK(ncclSend(d_send, count, ncclFloat, 0, c->comm, stream) == ncclSuccess);
-  }
-  CHECK(ncclGroupEnd() == ncclSuccess);
-}
-
 // ---------------------------------------------------------------- the two entry points
-// Sum-reduce `count` floats to rank 0 in place on the root (MPI_Reduce(SUM) of utils.cu:124-125).
-static void rt_reduce_sum(RtComm *c, float *d_buf, size_t count, hipStream_t stream) {
-  if (c->world <= 1) return;
-  CHECK(ncclReduce(d_buf, d_buf, count, ncclFloat, ncclSum, 0, c->comm, stream) == ncclSuccess);
-}
-
 // spp_split: the reference's decomposition (utils.cu:189,220,238) — every rank renders the WHOLE
 // frame with GetWorkload(rank, world, spp) samples and no post-process, frames are summed on rank 0
 // and the root applies sqrt(clamp(sum / spp)).  All ranks seed identically, as the reference does
@@ -598,12 +579,13 @@ static void rt_run(curandState **d_states, Camera **d_camera, HitableList **d_wo
               << " rays, " << (rays / (ms * 1e3)) << " Mrays/s)";
   }
 
+  // the exchange goes through the C ABI as well (rtmi_gather / rtmi_reduce_sum on this program's communicator)
   if (spp_split) {
-    rt_reduce_sum(comm, d_tiles, (size_t)items * 3, nullptr);
+    // MPI_Reduce(SUM) of utils.cu:124-125 on device buffers; `frame` is the whole frame here (every rank owns it)
+    if (comm->world > 1) RT_ABI(rtmi_reduce_sum(comm->comm, &frame, d_tiles, 0, nullptr));
     RT_HIP(hipDeviceSynchronize());
-  } else if (comm->world > 1) {
-    if (comm->rank == 0) RT_HIP(hipMemcpy(d_all, d_tiles, (size_t)items * 3 * sizeof(float), hipMemcpyDeviceToDevice));
-    rt_gather(comm, d_tiles, d_all, (size_t)items * 3, nullptr);
+  } else {
+    RT_ABI(rtmi_gather(comm->comm, &frame, d_tiles, d_all, 0, nullptr));
     RT_HIP(hipDeviceSynchronize());
   }
   if (comm->rank == 0) {

@@ -2,8 +2,11 @@
 // checking, the host-side scene recorder, uploads, and kernel launches.  There is
 // deliberately no CPU rendering path in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only: the entry points are looked up at run time (rtmi_gather)
 #include <string.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -51,6 +54,8 @@ static RenderTuning default_tuning() {
     g_tune.exclusive = env_int("RTMI_EXCLUSIVE", 1) ? 1 : 0;
     g_tune.outlier_x10 = env_int("RTMI_OUTLIER_X10", 20);
     if (g_tune.outlier_x10 < 1) g_tune.outlier_x10 = 20;
+    g_tune.head_pct[0] = 80, g_tune.head_pct[1] = 55, g_tune.head_pct[2] = 30;
+    g_tune.priority = env_int("RTMI_PRIORITY", 0) ? 1 : 0;
   });
   std::lock_guard<std::mutex> lk(g_tune_mu);
   return g_tune;
@@ -59,6 +64,11 @@ static RenderTuning default_tuning() {
 static Scene *S(rtmi_scene *s) { return reinterpret_cast<Scene *>(s); }
 static const Scene *S(const rtmi_scene *s) { return reinterpret_cast<const Scene *>(s); }
 static V3 v3(const float *p) { return mk(p[0], p[1], p[2]); }
+static bool all_finite(const float *p, size_t n) {
+  for (size_t i = 0; i < n; i++)
+    if (!std::isfinite(p[i])) return false;
+  return true;
+}
 
 static bool make_frame(const rtmi_frame *f, FrameDev *out) {
   if (!f || f->height <= 0 || f->width <= 0 || f->spp < 0 || f->world_size <= 0 || f->rank < 0 ||
@@ -205,12 +215,14 @@ static bool mat_ok(rtmi_scene *s, int m) { return m >= 0 && m < (int)S(s)->mats.
 
 int rtmi_add_sphere(rtmi_scene *s, const float c[3], double radius, int material) {
   if (!s || !c || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad sphere arguments");
+  if (!all_finite(c, 3) || !std::isfinite(radius)) return fail(RTMI_ERR_INVALID, "non-finite sphere");
   HostObj o{};
   o.kind = OBJ_SPHERE, o.mat = material, o.p[0] = v3(c), o.radius = radius;
   return append(s, o);
 }
 int rtmi_add_triangle(rtmi_scene *s, const float p[9], int material) {
   if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad triangle arguments");
+  if (!all_finite(p, 9)) return fail(RTMI_ERR_INVALID, "non-finite triangle corner");
   HostObj o{};
   o.kind = OBJ_TRI, o.mat = material;
   for (int i = 0; i < 3; i++) o.p[i] = v3(p + 3 * i);
@@ -218,6 +230,7 @@ int rtmi_add_triangle(rtmi_scene *s, const float p[9], int material) {
 }
 int rtmi_add_parallelogram(rtmi_scene *s, const float p[9], int material) {
   if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelogram arguments");
+  if (!all_finite(p, 9)) return fail(RTMI_ERR_INVALID, "non-finite parallelogram corner");
   HostObj o{};
   o.kind = OBJ_PGRAM, o.mat = material;
   for (int i = 0; i < 3; i++) o.p[i] = v3(p + 3 * i);
@@ -225,6 +238,7 @@ int rtmi_add_parallelogram(rtmi_scene *s, const float p[9], int material) {
 }
 int rtmi_add_parallelepiped(rtmi_scene *s, const float p[12], int material) {
   if (!s || !p || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelepiped arguments");
+  if (!all_finite(p, 12)) return fail(RTMI_ERR_INVALID, "non-finite parallelepiped corner");
   HostObj o{};
   o.kind = OBJ_BOX, o.mat = material;
   V3 c[4], corners[8];
@@ -253,11 +267,15 @@ int rtmi_add_parallelepiped_lengths(rtmi_scene *s, const float lengths[3], int m
     transform(q[i], t, user);
     corners[4 + i] = v3(t);
   }
+  for (int i = 0; i < 8; i++)
+    if (!std::isfinite(corners[i].x) || !std::isfinite(corners[i].y) || !std::isfinite(corners[i].z))
+      return fail(RTMI_ERR_INVALID, "the transform produced a non-finite parallelepiped corner");
   box_faces(corners, o.p);
   return append(s, o);
 }
 int rtmi_add_parallelepiped_faces(rtmi_scene *s, const float faces[54], int material) {
   if (!s || !faces || !mat_ok(s, material)) return fail(RTMI_ERR_INVALID, "bad parallelepiped arguments");
+  if (!all_finite(faces, 54)) return fail(RTMI_ERR_INVALID, "non-finite parallelepiped corner");
   HostObj o{};
   o.kind = OBJ_BOX, o.mat = material;
   for (int i = 0; i < 18; i++) o.p[i] = v3(faces + 3 * i);
@@ -286,6 +304,9 @@ int rtmi_add_sky(rtmi_scene *s) {
 int rtmi_add_bvh(rtmi_scene *s, const float *faces, const float *uvs, int n, int material, int leaf_max) {
   if (!s || n < 0 || (n > 0 && !faces)) return fail(RTMI_ERR_INVALID, "bad bvh arguments");
   if (material >= (int)S(s)->mats.size()) return fail(RTMI_ERR_INVALID, "unknown material handle");
+  // The reference would build such a mesh and simply never hit the face; here a non-finite coordinate would
+  // poison the bounds of the search tree, so the mesh is refused (the caller drops the face).
+  if (n > 0 && !all_finite(faces, (size_t)n * 9)) return fail(RTMI_ERR_INVALID, "non-finite face coordinate in the mesh");
   HostBvh b;
   b.n = n, b.mat = material, b.leaf_max = leaf_max > 0 ? leaf_max : 2048;
   b.faces.assign(faces, faces + (size_t)n * 9);
@@ -507,9 +528,13 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 }
 
 // ------------------------------------------------------------------ render
+// Per-call scratch: [ counters: RTMI_COUNTER_WORDS x 8 B ][ probe RNG states ][ probe ray counts ][ tile costs ]
+// [ tile order ][ 32 words of scheduler meta ][ head list: kHeadCap words ].  The counters come first so that
+// rtmi_render_status can find them from the scratch pointer alone.
+static constexpr size_t kCounterBytes = RTMI_COUNTER_WORDS * sizeof(unsigned long long);
 static size_t scratch_bytes_of(const FrameDev &d) {
   const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-  return n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4;
+  return kCounterBytes + n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4;
 }
 size_t rtmi_render_scratch_bytes(const rtmi_frame *f) {
   FrameDev d;
@@ -522,31 +547,39 @@ int rtmi_render(const rtmi_scene *sp, const rtmi_frame *f, void *d_states, float
   return rtmi_render_ex(sp, f, nullptr, d_states, d_tiles, d_ray_counts, stream);
 }
 
-int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
-                   float *d_tiles, uint32_t *d_ray_counts, void *stream) {
-  if (!sp || !d_states || !d_tiles) return fail(RTMI_ERR_INVALID, "null argument");
-  RenderTuning tune = default_tuning();
-  void *user_scratch = nullptr;
-  size_t user_scratch_bytes = 0;
-  if (opts) {
-    if (opts->size != (int32_t)sizeof(rtmi_render_opts)) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.size does not match this library");
-    if (opts->schedule > 2 || opts->blocks_per_cu < 0 || opts->threads_per_block < 0 || (opts->threads_per_block % 64) != 0 ||
-        opts->threads_per_block > 512 || (opts->sparse_stride != 0 && !valid_stride(opts->sparse_stride)) || opts->exclusive > 1 ||
-        opts->outlier_x10 < 0)
-      return fail(RTMI_ERR_INVALID, "rtmi_render_opts field out of range");
-    if (opts->schedule >= 0) tune.schedule = opts->schedule;
-    if (opts->blocks_per_cu > 0) tune.blocks_per_cu = opts->blocks_per_cu;
-    if (opts->threads_per_block > 0) tune.threads = opts->threads_per_block;
-    if (opts->sparse_stride > 0) tune.sparse_stride = opts->sparse_stride;
-    if (opts->exclusive >= 0) tune.exclusive = opts->exclusive;
-    if (opts->outlier_x10 > 0) tune.outlier_x10 = opts->outlier_x10;
-    user_scratch = opts->d_scratch, user_scratch_bytes = opts->scratch_bytes;
-  }
-  const Scene *s = S(sp);
-  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
-  FrameDev d;
-  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
-  if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
+// rtmi_render_opts over the process defaults -> the tuning of ONE call.
+static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void **scratch, size_t *scratch_bytes) {
+  *tune = default_tuning();
+  *scratch = nullptr, *scratch_bytes = 0;
+  if (!opts) return RTMI_OK;
+  if (opts->size != (int32_t)sizeof(rtmi_render_opts)) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.size does not match this library");
+  if (opts->schedule > 2 || opts->blocks_per_cu < 0 || opts->threads_per_block < 0 || (opts->threads_per_block % 64) != 0 ||
+      opts->threads_per_block > 512 || (opts->sparse_stride != 0 && !valid_stride(opts->sparse_stride)) || opts->exclusive > 1 ||
+      opts->outlier_x10 < 0 || opts->priority > 1)
+    return fail(RTMI_ERR_INVALID, "rtmi_render_opts field out of range");
+  for (int i = 0; i < 3; i++)
+    if (opts->head_pct[i] < 0 || opts->head_pct[i] > 100) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.head_pct outside [0, 100]");
+  if (opts->schedule >= 0) tune->schedule = opts->schedule;
+  if (opts->blocks_per_cu > 0) tune->blocks_per_cu = opts->blocks_per_cu;
+  if (opts->threads_per_block > 0) tune->threads = opts->threads_per_block;
+  if (opts->sparse_stride > 0) tune->sparse_stride = opts->sparse_stride;
+  if (opts->exclusive >= 0) tune->exclusive = opts->exclusive;
+  if (opts->outlier_x10 > 0) tune->outlier_x10 = opts->outlier_x10;
+  if (opts->priority >= 0) tune->priority = opts->priority;
+  for (int i = 0; i < 3; i++)
+    if (opts->head_pct[i] > 0) tune->head_pct[i] = opts->head_pct[i];
+  if (!(tune->head_pct[0] >= tune->head_pct[1] && tune->head_pct[1] >= tune->head_pct[2]))
+    return fail(RTMI_ERR_INVALID, "rtmi_render_opts.head_pct must not increase from the heaviest class to the lightest");
+  *scratch = opts->d_scratch, *scratch_bytes = opts->scratch_bytes;
+  return RTMI_OK;
+}
+
+// Kernel variant and launch shape of a frame on the current device.
+struct LaunchShape {
+  uint32_t variant;
+  int threads, per_cu, blocks, n_cu;
+};
+static int launch_shape(const Scene *s, const FrameDev &d, const RenderTuning &tune, LaunchShape *out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   if (dev != s->device) return fail(RTMI_ERR_INVALID, "scene was committed on another device");
@@ -579,7 +612,53 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   int64_t cap = (int64_t)n_cu * per_cu;
   int blocks = (int)(want < cap ? want : cap);
   if (blocks < 1) blocks = 1;
+  out->variant = variant, out->threads = threads, out->per_cu = per_cu, out->blocks = blocks, out->n_cu = n_cu;
+  return RTMI_OK;
+}
+
+int rtmi_render_launch_shape(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[4]) {
+  if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  RenderTuning tune;
+  void *scratch;
+  size_t scratch_bytes;
+  int rc = resolve_opts(opts, &tune, &scratch, &scratch_bytes);
+  if (rc) return rc;
+  LaunchShape ls;
+  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
+  out[0] = ls.blocks, out[1] = ls.threads, out[2] = ls.per_cu, out[3] = ls.n_cu;
+  return RTMI_OK;
+}
+
+int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
+                   float *d_tiles, uint32_t *d_ray_counts, void *stream) {
+  if (!sp || !d_states || !d_tiles) return fail(RTMI_ERR_INVALID, "null argument");
+  RenderTuning tune;
+  void *user_scratch = nullptr;
+  size_t user_scratch_bytes = 0;
+  int rc = resolve_opts(opts, &tune, &user_scratch, &user_scratch_bytes);
+  if (rc) return rc;
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
+  LaunchShape ls;
+  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
+  const uint32_t variant = ls.variant;
+  const int threads = ls.threads, blocks = ls.blocks;
   hipStream_t st = (hipStream_t)stream;
+  const size_t need = scratch_bytes_of(d);
+  if (user_scratch && user_scratch_bytes < need)
+    return fail(RTMI_ERR_INVALID, "rtmi_render_opts.scratch_bytes < rtmi_render_scratch_bytes(frame)");
+  // Every piece of device state of this call -- queue cursors, ray total, abandoned-search flag, the scheduler's
+  // buffers -- lives in the caller's scratch when one is given: renders of one scene on several streams (or as N
+  // shards on one device) then share nothing but the read-only scene.  Without one the scene's own (a cache, not
+  // scene state) is used, which ties renders of this scene to one at a time.
+  unsigned long long *counters = user_scratch ? reinterpret_cast<unsigned long long *>(user_scratch) : s->d_counters;
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
   SchedPlan plan;
@@ -587,13 +666,8 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   const bool many_tiles = (int64_t)d.local_tiles * 64 > (int64_t)blocks * threads;
   if (tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
     const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-    const size_t need = scratch_bytes_of(d);
     void *scratch = user_scratch;
-    if (scratch) {
-      if (user_scratch_bytes < need) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.scratch_bytes < rtmi_render_scratch_bytes(frame)");
-    } else {
-      // no scratch from the caller: the scene keeps one (a cache, not scene state), which ties renders
-      // of this scene to one stream at a time
+    if (!scratch) {
       Scene *ms = const_cast<Scene *>(s);
       std::lock_guard<std::mutex> lk(g_mu);  // (re)allocation only
       if (ms->sched_bytes < need) {
@@ -604,7 +678,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
       }
       scratch = ms->d_sched;
     }
-    uint32_t *p_states = reinterpret_cast<uint32_t *>(scratch);
+    uint32_t *p_states = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(scratch) + kCounterBytes);
     uint32_t *p_rays = p_states + n * RTMI_STATE_WORDS;
     uint32_t *p_cost = p_rays + n;
     uint32_t *p_order = p_cost + nt;
@@ -612,9 +686,9 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
     probe.spp = probe_spp;
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
-    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, s->d_counters, SchedPlan(), true, blocks,
+    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, counters, SchedPlan(), true, blocks,
                           threads, tune, st));
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
     // the head of a mesh frame's queue: pixels in weight classes (the default), or -- when the call names a
@@ -623,37 +697,47 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     const bool by_pixels = head_classes && !(opts && opts->sparse_stride > 0);
     uint32_t *p_head = (variant & F_BVH) && by_pixels ? p_meta + 32 : nullptr;
     HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, p_head, sparse_cap, blocks * (threads / 64),
-                              tune.outlier_x10, st));
+                              tune.outlier_x10, tune.head_pct, st));
     plan.tile_order = p_order;
     plan.sparse_items = p_meta + 1;
     plan.head_list = p_head;
     plan.probe_marks = p_head ? p_rays : nullptr;
   }
-  HIP_TRY(hipMemsetAsync(s->d_counters, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long), st));
-  HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts,
-                        s->d_counters, plan, false, blocks, threads, tune, st));
+  HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
+  HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts, counters,
+                        plan, false, blocks, threads, tune, st));
   return RTMI_OK;
 }
 
-int rtmi_last_ray_total(const rtmi_scene *sp, uint64_t *out_rays, void *stream) {
-  if (!sp || !out_rays) return fail(RTMI_ERR_INVALID, "null argument");
+int rtmi_render_status(const rtmi_scene *sp, const void *d_scratch, uint64_t *out_rays, void *stream) {
+  if (!sp) return fail(RTMI_ERR_INVALID, "null argument");
   const Scene *s = S(sp);
   if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  const unsigned long long *counters = d_scratch ? reinterpret_cast<const unsigned long long *>(d_scratch) : s->d_counters;
   unsigned long long v[2] = {0, 0};  // [0] rays, [1] abandoned mesh searches (must be 0)
-  HIP_TRY(hipMemcpyAsync(v, s->d_counters + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_TRY(hipMemcpyAsync(v, counters + 1, sizeof(v), hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  *out_rays = v[0];
+  if (out_rays) *out_rays = v[0];
   if (v[1] != 0) return fail(RTMI_ERR_INTERNAL, "mesh search stack overflow: the frame is incomplete");
   return RTMI_OK;
 }
 
-// Diagnostic: the raw counter words of the most recent render (RTMI_STATS builds fill words 4..16).
+int rtmi_last_ray_total(const rtmi_scene *sp, uint64_t *out_rays, void *stream) {
+  if (!out_rays) return fail(RTMI_ERR_INVALID, "null argument");
+  return rtmi_render_status(sp, nullptr, out_rays, stream);
+}
+
+// Diagnostic: the raw counter words of the most recent render (RTMI_STATS builds fill words 4..32).
 int rtmi_debug_counters(const rtmi_scene *sp, unsigned long long out[RTMI_COUNTER_WORDS], void *stream) {
+  return rtmi_debug_counters_ex(sp, nullptr, out, stream);
+}
+int rtmi_debug_counters_ex(const rtmi_scene *sp, const void *d_scratch, unsigned long long out[RTMI_COUNTER_WORDS],
+                           void *stream) {
   if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
   const Scene *s = S(sp);
   if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
-  HIP_TRY(hipMemcpyAsync(out, s->d_counters, RTMI_COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                         (hipStream_t)stream));
+  const unsigned long long *counters = d_scratch ? reinterpret_cast<const unsigned long long *>(d_scratch) : s->d_counters;
+  HIP_TRY(hipMemcpyAsync(out, counters, kCounterBytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
   return RTMI_OK;
 }
@@ -666,6 +750,84 @@ int rtmi_debug_wave_stats(unsigned long long *out, size_t bytes) {
   return RTMI_OK;
 }
 #endif
+
+// ------------------------------------------------------------------ exchange
+// RCCL is not a link-time dependency of this library: the caller owns the communicator, so its RCCL is already
+// in the process (a second copy must not be pulled in next to e.g. the one PyTorch bundles).  The four entry points
+// are taken from the process image, or from librccl.so.1 when nothing has loaded it yet.
+namespace {
+struct Rccl {
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclReduce) reduce = nullptr;
+  decltype(&ncclGetErrorString) err = nullptr;
+  bool ok = false;
+};
+const Rccl &rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    void *h = RTLD_DEFAULT;
+    if (!dlsym(h, "ncclSend")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return x;
+    x.group_start = reinterpret_cast<decltype(x.group_start)>(dlsym(h, "ncclGroupStart"));
+    x.group_end = reinterpret_cast<decltype(x.group_end)>(dlsym(h, "ncclGroupEnd"));
+    x.send = reinterpret_cast<decltype(x.send)>(dlsym(h, "ncclSend"));
+    x.recv = reinterpret_cast<decltype(x.recv)>(dlsym(h, "ncclRecv"));
+    x.reduce = reinterpret_cast<decltype(x.reduce)>(dlsym(h, "ncclReduce"));
+    x.err = reinterpret_cast<decltype(x.err)>(dlsym(h, "ncclGetErrorString"));
+    x.ok = x.group_start && x.group_end && x.send && x.recv && x.reduce;
+    return x;
+  }();
+  return r;
+}
+int rccl_fail(const Rccl &R, ncclResult_t e, const char *what) {
+  return fail(RTMI_ERR_HIP, std::string(what) + ": " + (R.err ? R.err(e) : "RCCL error"));
+}
+}  // namespace
+#define RCCL_TRY(expr)                                        \
+  do {                                                        \
+    ncclResult_t e__ = (expr);                                \
+    if (e__ != ncclSuccess) return rccl_fail(R, e__, #expr);  \
+  } while (0)
+
+int rtmi_gather(void *nccl_comm, const rtmi_frame *f, const float *d_tiles, float *d_all_tiles, int root, void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_tiles || root < 0 || root >= d.world) return fail(RTMI_ERR_INVALID, "bad gather arguments");
+  if (d.rank == root && !d_all_tiles) return fail(RTMI_ERR_INVALID, "the root needs d_all_tiles");
+  const size_t count = (size_t)d.items * 3;
+  hipStream_t st = (hipStream_t)stream;
+  if (d.rank == root && d_all_tiles + (size_t)root * count != d_tiles)
+    HIP_TRY(hipMemcpyAsync(d_all_tiles + (size_t)root * count, d_tiles, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (d.world == 1) return RTMI_OK;
+  if (!nccl_comm) return fail(RTMI_ERR_INVALID, "world_size > 1 needs an RCCL communicator");
+  const Rccl &R = rccl();
+  if (!R.ok) return fail(RTMI_ERR_NO_DEVICE, "RCCL (librccl.so.1) is not available in this process");
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+  // xGMI is point to point and every peer has a direct link to the root: one grouped round of sends, no ring
+  RCCL_TRY(R.group_start());
+  if (d.rank == root) {
+    for (int r = 0; r < d.world; r++)
+      if (r != root) RCCL_TRY(R.recv(d_all_tiles + (size_t)r * count, count, ncclFloat, r, comm, st));
+  } else {
+    RCCL_TRY(R.send(d_tiles, count, ncclFloat, root, comm, st));
+  }
+  RCCL_TRY(R.group_end());
+  return RTMI_OK;
+}
+
+int rtmi_reduce_sum(void *nccl_comm, const rtmi_frame *f, float *d_tiles, int root, void *stream) {
+  FrameDev d;
+  if (!make_frame(f, &d) || !d_tiles || root < 0) return fail(RTMI_ERR_INVALID, "bad reduce arguments");
+  if (!nccl_comm) return RTMI_OK;  // a single rank: its sum is the sum
+  const Rccl &R = rccl();
+  if (!R.ok) return fail(RTMI_ERR_NO_DEVICE, "RCCL (librccl.so.1) is not available in this process");
+  RCCL_TRY(R.reduce(d_tiles, d_tiles, (size_t)d.items * 3, ncclFloat, ncclSum, root, reinterpret_cast<ncclComm_t>(nccl_comm),
+                    (hipStream_t)stream));
+  return RTMI_OK;
+}
 
 int rtmi_untile(const rtmi_frame *f, const float *d_all_tiles, float *d_image, void *stream) {
   FrameDev d;

@@ -30,6 +30,9 @@ struct RenderTuning {
   int sparse_stride;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two, 1..64)
   int exclusive;      // 1: a wave holding an outlier pixel takes no other new pixels (its lanes work for it)
   int outlier_x10;    // a tile is an outlier from this many tenths of the mean tile cost
+  int head_pct[3];    // mesh frames: per cent of the frame's largest probe count from which a pixel gets a wave to itself,
+                      // shares one with another, gets one lane in 16 (80 / 55 / 30)
+  int priority;       // 1: waves raise their issue priority with the rank of the tiles they hold in the longest-first order
 };
 // What the scheduler's probe pass leaves for the real pass (device pointers, all optional).
 struct SchedPlan {
@@ -51,7 +54,7 @@ hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &f
 constexpr int kHeadCap = 16384;
 hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
-                             hipStream_t stream);
+                             const int head_pct[3], hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void head_scatter_kernel(uint32_t *__restrict_
 
 hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
-                             hipStream_t stream) {
+                             const int head_pct[3], hipStream_t stream) {
   hipError_t e = hipMemsetAsync(d_meta, 0, 32 * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(tile_cost_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_ray_counts, n_tiles, d_cost,
@@ -319,9 +319,7 @@ hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_co
   hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, stream, d_cost, d_meta, n_tiles, d_order, d_meta + 1,
                      sparse_cap, (uint32_t)outlier_x10);
   if (d_head) {
-    static const int p64 = [] { const char *e = getenv("RTMI_T64"); return e && *e ? atoi(e) : 80; }();
-    static const int p32 = [] { const char *e = getenv("RTMI_T32"); return e && *e ? atoi(e) : 55; }();
-    static const int p16 = [] { const char *e = getenv("RTMI_T16"); return e && *e ? atoi(e) : 30; }();
+    const int p64 = head_pct[0], p32 = head_pct[1], p16 = head_pct[2];  // (rtmi_render_opts.head_pct)
     uint32_t *ws = d_meta + 16;  // 16 words of workspace behind the 16 of d_meta (zeroed with them)
     const int n_items = n_tiles * 64, blocks = n_items / 4096 > 0 ? (n_items / 4096 < 1024 ? n_items / 4096 : 1024) : 1;
     hipLaunchKernelGGL(head_scan_kernel, dim3(blocks), dim3(256), 0, stream, d_ray_counts, n_items, ws);
@@ -433,6 +431,7 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.probe_marks = plan.probe_marks;
   lc.sparse_stride = tune.sparse_stride;
   lc.exclusive = tune.exclusive;
+  lc.priority = probe ? 0 : tune.priority;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),

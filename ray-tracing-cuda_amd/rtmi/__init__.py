@@ -34,13 +34,20 @@ class RenderOpts(C.Structure):
     """rtmi_render_opts of include/rtmi.h (per-call scheduling options)."""
     _fields_ = [("size", C.c_int32), ("schedule", C.c_int32), ("blocks_per_cu", C.c_int32),
                 ("threads_per_block", C.c_int32), ("sparse_stride", C.c_int32), ("exclusive", C.c_int32),
-                ("outlier_x10", C.c_int32), ("reserved", C.c_int32), ("d_scratch", C.c_void_p),
-                ("scratch_bytes", C.c_size_t)]
+                ("outlier_x10", C.c_int32), ("priority", C.c_int32), ("head_pct", C.c_int32 * 3),
+                ("reserved", C.c_int32), ("d_scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
 
 
-def render_opts(schedule=-1, blocks_per_cu=0, threads_per_block=0, sparse_stride=0, exclusive=-1, outlier_x10=0):
-    return RenderOpts(C.sizeof(RenderOpts), schedule, blocks_per_cu, threads_per_block, sparse_stride, exclusive,
-                      outlier_x10, 0, None, 0)
+def render_opts(schedule=-1, blocks_per_cu=0, threads_per_block=0, sparse_stride=0, exclusive=-1, outlier_x10=0,
+                priority=-1, head_pct=(0, 0, 0), scratch=None):
+    """``scratch``: a torch uint8/int32 CUDA tensor of at least ``scratch_bytes(frame)`` bytes that holds ALL
+    per-call state of the render (keep it alive until the render has finished)."""
+    o = RenderOpts(C.sizeof(RenderOpts), schedule, blocks_per_cu, threads_per_block, sparse_stride, exclusive,
+                   outlier_x10, priority, (C.c_int32 * 3)(*head_pct), 0, None, 0)
+    if scratch is not None:
+        o.d_scratch = scratch.data_ptr()
+        o.scratch_bytes = scratch.numel() * scratch.element_size()
+    return o
 
 
 TRANSFORM_FN = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
@@ -95,8 +102,13 @@ SYMBOLS = [
     ("rtmi_render", C.c_int, [C.c_void_p, _frp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_render_ex", C.c_int, [C.c_void_p, _frp, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_render_scratch_bytes", C.c_size_t, [_frp]),
+    ("rtmi_render_launch_shape", C.c_int, [C.c_void_p, _frp, C.POINTER(RenderOpts), C.POINTER(C.c_int32)]),
+    ("rtmi_render_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     ("rtmi_last_ray_total", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     ("rtmi_debug_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_void_p]),
+    ("rtmi_debug_counters_ex", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_ulonglong), C.c_void_p]),
+    ("rtmi_gather", C.c_int, [C.c_void_p, _frp, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    ("rtmi_reduce_sum", C.c_int, [C.c_void_p, _frp, C.c_void_p, C.c_int, C.c_void_p]),
     ("rtmi_untile", C.c_int, [_frp, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_untile_u32", C.c_int, [_frp, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_post_process", C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
@@ -321,6 +333,7 @@ class Renderer:
     def render(self, count_rays=True, opts=None):
         """Enqueue the trace kernel on torch's current stream (asynchronous).  ``opts``: a
         ``render_opts(...)`` structure with per-call scheduling options (None = the defaults)."""
+        self._last_scratch = opts.d_scratch if opts is not None else None
         with self.torch.cuda.device(self.device):
             rc = self.L.rtmi_render_ex(self.scene.h, C.byref(self.frame), C.byref(opts) if opts is not None else None,
                                        C.c_void_p(self.states.data_ptr()), C.c_void_p(self.tiles.data_ptr()),
@@ -328,10 +341,36 @@ class Renderer:
         _check(rc, "rtmi_render_ex")
         return self
 
-    def total_rays(self):
+    def check(self):
+        """Wait for the last render and raise if it reported an incomplete frame (rtmi_render_status)."""
+        with self.torch.cuda.device(self.device):
+            _check(self.L.rtmi_render_status(self.scene.h, C.c_void_p(getattr(self, "_last_scratch", None)), None,
+                                             self._stream()), "rtmi_render_status")
+        return self
+
+    def scratch_bytes(self):
+        return int(self.L.rtmi_render_scratch_bytes(C.byref(self.frame)))
+
+    def new_scratch(self):
+        """Device memory for the per-call state of one render (``render_opts(scratch=...)``)."""
+        return self.torch.zeros((self.scratch_bytes() + 7) // 8, dtype=self.torch.int64, device=self.device)
+
+    def launch_shape(self, opts=None):
+        """{workgroups, lanes per workgroup, workgroups per CU, CUs} of a render of this frame."""
+        out = (C.c_int32 * 4)()
+        with self.torch.cuda.device(self.device):
+            _check(self.L.rtmi_render_launch_shape(self.scene.h, C.byref(self.frame),
+                                                   C.byref(opts) if opts is not None else None, out),
+                   "rtmi_render_launch_shape")
+        return dict(zip(("blocks", "threads", "blocks_per_cu", "compute_units"), list(out)))
+
+    def total_rays(self, scratch=None):
+        """Closest-hit queries of the last render (of the one that used ``scratch``, if given); raises when that
+        render reported an incomplete frame."""
         out = C.c_uint64(0)
         with self.torch.cuda.device(self.device):
-            _check(self.L.rtmi_last_ray_total(self.scene.h, C.byref(out), self._stream()), "rtmi_last_ray_total")
+            _check(self.L.rtmi_render_status(self.scene.h, C.c_void_p(scratch.data_ptr()) if scratch is not None else None,
+                                             C.byref(out), self._stream()), "rtmi_render_status")
         return out.value
 
     def untile(self, all_tiles=None, all_counts=None):
@@ -339,6 +378,8 @@ class Renderer:
         torch = self.torch
         f = self.frame
         with torch.cuda.device(self.device):
+            if all_tiles is None:  # this rank's own render: an incomplete frame must not be handed on
+                self.check()
             tiles = self.tiles if all_tiles is None else all_tiles
             assert tiles.numel() == self.items * 3 * f.world_size, "expected the buffers of all ranks back to back"
             img = torch.zeros((f.height, f.width, 3), dtype=torch.float32, device=self.device)

@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in sorted(declared):
         assert hasattr(L, name), "librtmi.so does not export %s" % name
         assert name in bound, "%s is not bound in rtmi.SYMBOLS" % name
-    assert L.rtmi_version() == 1
+    assert L.rtmi_version() == 2
 
 
 def test_float_thresholds_used_by_the_kernel():

@@ -12,7 +12,7 @@ R = rtmi.Renderer(b, 1024, 1024, spp, 50).init_rng()
 R.render(); torch.cuda.synchronize()
 out = (C.c_ulonglong * 32)()
 rtmi.lib().rtmi_debug_counters(b.h, out, None)
-rays, wq, bits, iters, crays = out[1], out[4], out[30], out[31], out[3]
+rays, wq, bits, iters, crays = out[1], out[4], out[30], out[31], out[32]
 life = out[26]
 names = ["gen", "list", "search", "replay", "shade", "cull", "tasks+tests+fold", "fold"]
 for i, n in enumerate(names):

@@ -11,8 +11,16 @@ import os
 import sys
 
 out, tag, wls = sys.argv[1], sys.argv[2], sys.argv[3:]
-SIZES = {"c2": ("cornell_box", "1024x1024x1024_d50"), "c3": ("bunny", "1024x1024x512_d10"),
-         "c4": ("cornell_box", "2048x2048x4096_d50"), "c5": ("birthday", "4096x4096x8192_d10")}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402  (WORKLOADS, roofline_key, kernel_source_hash: one definition of the digest's keys)
+
+
+def shape_of(wl):
+    """workload tag of tools/profile_bench.sh -> (scene, digest key); "c4s0of8" = shard 0 of 8 of c4."""
+    name, _, sh = wl.partition("s") if wl[:2] in ("c4", "c5") and "s" in wl[2:] else (wl, "", "")
+    w = bench.WORKLOADS[name]
+    shard = tuple(int(x) for x in sh.split("of")) if sh else None
+    return w["scene"], bench.roofline_key(w, shard)
 
 
 def rows(pattern):
@@ -40,9 +48,9 @@ digest["bench_full"] = last_json(os.path.join(out, "trace.log"))
 inputs = {"note": "instruction mix and HBM bytes of ONE launch of render_kernel per workload, from separate rocprofv3 "
                   "--pmc passes (tools/profile_bench.sh); bench.py's roofline multiplies the per-64-rays counts by the "
                   "rays of its own run and divides by its own HIP-event kernel time",
-          "tag": tag, "kernels": {}}
+          "tag": tag, "kernel_source_hash": bench.kernel_source_hash(), "kernels": {}}
 for wl in wls:
-    scene, key = SIZES[wl]
+    scene, key = shape_of(wl)
     pmc = {}
     for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
         per = {}
@@ -79,7 +87,7 @@ for wl in wls:
         entry = {"valu_per_64_rays": d["valu_per_64_rays"], "trans_per_64_rays": d["trans_per_64_rays"],
                  "salu_per_64_rays": d["salu_per_64_rays"], "vgpr": pmc.get("_vgpr"), "sgpr": pmc.get("_sgpr"),
                  "lds_bytes": pmc.get("_lds"), "profiled_kernel_ms": ms,
-                 "source": "profiles/%s_summary.json (%s)" % (tag, wl), "hbm_bytes_per_launch": {}}
+                 "source": "profiles/%s_summary.json (%s)" % (tag, wl), "hbm_bytes_per_launch": None}
         if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
             # FETCH_SIZE / WRITE_SIZE are in KiB.  The gfx950 x2 correction of MI355X_MICROARCH.md applies to wide
             # coalesced streaming reads; this kernel's HBM traffic is narrow (dword RNG-state / radiance accesses,
@@ -87,8 +95,8 @@ for wl in wls:
             b = (pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024.0
             d["hbm_bytes_per_launch"] = b
             d["hbm_fetch_bytes"], d["hbm_write_bytes"] = pmc["FETCH_SIZE"] * 1024.0, pmc["WRITE_SIZE"] * 1024.0
-            entry["hbm_bytes_per_launch"][key] = b
-        inputs["kernels"][scene] = entry
+            entry["hbm_bytes_per_launch"] = b
+        inputs["kernels"].setdefault(scene, {"shapes": {}})["shapes"][key] = entry
     digest[wl] = d
 json.dump(inputs, open(os.path.join(out, "roofline_inputs.json"), "w"), indent=1)
 digest["copy"] = ["cp gpurun_out/%s/%s_summary.json profiles/" % (tag, tag),
