@@ -190,15 +190,20 @@ def test_render_opts_validation():
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(bad_size), dummy, dummy, None, None) == -1
     assert b"size" in L.rtmi_last_error()
     for kw in (dict(schedule=3), dict(threads_per_block=100), dict(threads_per_block=1024), dict(sparse_stride=12),
-               dict(exclusive=2), dict(blocks_per_cu=-1)):
+               dict(exclusive=2), dict(blocks_per_cu=-1), dict(priority=2)):
         o = rtmi.render_opts(**kw)
         assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1, kw
         assert b"out of range" in L.rtmi_last_error()
-    ok = rtmi.render_opts(schedule=2, sparse_stride=8, exclusive=0)
+    for pct in ((101, 0, 0), (0, -1, 0)):
+        o = rtmi.render_opts(head_pct=pct)
+        assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1 and b"head_pct" in L.rtmi_last_error()
+    o = rtmi.render_opts(head_pct=(40, 50, 30))  # the classes' thresholds must not increase
+    assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1 and b"must not increase" in L.rtmi_last_error()
+    ok = rtmi.render_opts(schedule=2, sparse_stride=8, exclusive=0, priority=1, head_pct=(90, 60, 20))
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(ok), dummy, dummy, None, None) == -1
     assert b"not committed" in L.rtmi_last_error()  # the options passed; the scene is what is missing
-    # states copy + probe counts + tile costs and order + 16 words + the head list (16,384 entries)
-    assert L.rtmi_render_scratch_bytes(C.byref(fr)) == 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 128 + 16384 * 4
+    # the call's counters + states copy + probe counts + tile costs and order + 32 words + the head list (16,384 entries)
+    assert L.rtmi_render_scratch_bytes(C.byref(fr)) == 40 * 8 + 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 128 + 16384 * 4
 
 
 def test_no_cpu_fallback():
