@@ -250,7 +250,9 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
         R.render(opts=opts)
         if ev:
             ev[1].record()
-        if use_dist and not shard:
+        if shard:
+            R.check()  # one shard of G: there is no frame to assemble on this GPU
+        elif use_dist:
             R.check()  # an incomplete frame raises here, before it is handed on
             allt = gather_to_root(R.tiles, 0)
             if rank == 0:

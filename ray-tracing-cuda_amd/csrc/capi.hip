@@ -388,6 +388,7 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->tris, &d.tris))) return rc;
   if ((rc = upload(s, s->pair_boxes, &d.pair_boxes))) return rc;
   if ((rc = upload(s, s->pair_pts, &d.pair_pts))) return rc;
+  if ((rc = upload(s, s->tri_nrm, &d.tri_nrm))) return rc;
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
   if ((rc = upload(s, s->qnodes, &d.qnodes))) return rc;

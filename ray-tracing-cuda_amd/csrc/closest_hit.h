@@ -79,22 +79,41 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         const float hi0 = (float)t_to * 1.0001f + 1e-6f;
         uint32_t mask = 0u;
         RTMI_STAT2(const unsigned long long tc0 = stat_now();)
-        f32x8 nxt = load_pair_box(sc.pair_boxes, pair0 + c0);
-        for (int i = 0; i < nc; i++) {
+        // t = (plane -+ delta - o) / d as one FMA per plane: plane * (1/d) - (o +- delta) * (1/d).  The rounding of
+        // the two products is an error of ~6e-8 of the plane's coordinate in space, far inside delta.
+        // Two SGPR buffers ping-pong (A, B: the loop is unrolled by hand so that no buffer is ever copied); the
+        // verdict of pair i is shifted into `mask` from below (cull_step), bit nc - 1 - i, and the mask is turned
+        // round once at the end.
+#define RTMI_CULL_PAIR(bx)                                                                                                      \
+  {                                                                                                                             \
+    const float t0x = __builtin_fmaf(bx[0], cull_inv.x, cull_klo.x), t1x = __builtin_fmaf(bx[3], cull_inv.x, cull_khi.x); \
+    const float t0y = __builtin_fmaf(bx[1], cull_inv.y, cull_klo.y), t1y = __builtin_fmaf(bx[4], cull_inv.y, cull_khi.y); \
+    const float t0z = __builtin_fmaf(bx[2], cull_inv.z, cull_klo.z), t1z = __builtin_fmaf(bx[5], cull_inv.z, cull_khi.z); \
+    const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));                                            \
+    const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));                                            \
+    cull_step(mask, fmaxf(lo0, en), fminf(hi0, le));                                                                            \
+  }
+        f32x8 A = load_pair_box(sc.pair_boxes, pair0 + c0), B;
+        int i = 0;
+        for (; i + 1 < nc; i += 2) {
           __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the plain scan below
           __builtin_amdgcn_sched_barrier(0);
-          const f32x8 bx = nxt;
-          nxt = load_pair_box(sc.pair_boxes, pair0 + c0 + i + 1);  // (one inert record of padding at the end)
+          B = load_pair_box(sc.pair_boxes, pair0 + c0 + i + 1);
           __builtin_amdgcn_sched_barrier(0);
-          // t = (plane -+ delta - o) / d as one FMA per plane: plane * (1/d) - (o +- delta) * (1/d).  The rounding of
-          // the two products is an error of ~6e-8 of the plane's coordinate in space, far inside delta.
-          const float t0x = __builtin_fmaf(bx[0], cull_inv.x, cull_klo.x), t1x = __builtin_fmaf(bx[3], cull_inv.x, cull_khi.x);
-          const float t0y = __builtin_fmaf(bx[1], cull_inv.y, cull_klo.y), t1y = __builtin_fmaf(bx[4], cull_inv.y, cull_khi.y);
-          const float t0z = __builtin_fmaf(bx[2], cull_inv.z, cull_klo.z), t1z = __builtin_fmaf(bx[5], cull_inv.z, cull_khi.z);
-          const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-          const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-          mask |= fmaxf(lo0, en) <= fminf(hi0, le) ? 1u << i : 0u;
+          RTMI_CULL_PAIR(A)
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_sched_barrier(0);
+          A = load_pair_box(sc.pair_boxes, pair0 + c0 + i + 2);  // (one inert record of padding at the end)
+          __builtin_amdgcn_sched_barrier(0);
+          RTMI_CULL_PAIR(B)
         }
+        if (i < nc) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_sched_barrier(0);
+          RTMI_CULL_PAIR(A)
+        }
+#undef RTMI_CULL_PAIR
+        mask = __brev(mask) >> (32 - nc);  // bit i = pair i of the chunk (1 <= nc <= 32)
         if (!live) mask = 0u;  // a lane without a ray of its own only helps
         RTMI_STAT2(const unsigned long long tc1 = stat_now(); st.cyc[5] += tc1 - tc0;)
         RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
@@ -110,10 +129,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           constexpr int RW = (F & F_TEX) ? 6 : 2;  // result words per task: t of the two triangles (+ their u, v)
           int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks;
           const int cnt = __builtin_popcount(mask);
-          int base = 0;
-#pragma unroll
-          for (int bit = 0; bit < 6; bit++)
-            base += lane_rank(__builtin_amdgcn_ballot_w64(((cnt >> bit) & 1) != 0)) << bit;
+          const int base = wave_prefix_excl(cnt);
           if (cnt != 0) {
             int *rr = ll + lane * 8;
             int w3 = 0, w7 = 0;
@@ -390,10 +406,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           const int depth_r = br.ref_depth;
           const int log_d = depth_r < 8 ? 3 : depth_r < 16 ? 4 : 5;  // a leaf's row: its path code + the crossing times, 8, 16 or 32 words
           const int rows_max = (kMeshStackWords - 64) >> log_d;
-          // exclusive prefix sum of nleaf (0..4) over the wave, bit plane by bit plane: no LDS round trips
-          const int base = lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 1) != 0)) +
-                           2 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 2) != 0)) +
-                           4 * lane_rank(__builtin_amdgcn_ballot_w64((nleaf & 4) != 0));
+          // exclusive prefix sum of nleaf (0..4) over the wave in registers: no LDS round trips
+          const int base = wave_prefix_excl(nleaf);
           int *leaves = wl + 64 * kMeshRayWords;  // [64] one word per listed leaf of this round
           int *times = leaves + 64;                // rows of crossing times
 #if defined(RTMI_ABLATE) && RTMI_ABLATE == 4

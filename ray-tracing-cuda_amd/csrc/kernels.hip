@@ -412,7 +412,9 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t poff = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
   const bool cull = (variant & F_TRIS) && sc.n_pairs >= kCullMinPairs && sc.n_pairs <= kLdsPairs && !plain_list_scan();
   lc.pairs_off = cull ? (int32_t)poff : -1;
-  size_t loff = (poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
+  size_t noff2 = (poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
+  lc.nrm_off = cull ? (int32_t)noff2 : -1;
+  size_t loff = (noff2 + (cull ? (size_t)sc.n_pairs * 2 * sizeof(TriNrm) : 0) + 15) & ~(size_t)15;
   const bool share = cull;  // the culled scan always shares its candidate tests over the wave
   lc.list_off = share ? (int32_t)loff : -1;
   *lds_bytes = loff + (share ? (size_t)(threads / 64) * (64 * 8 + kListTasks * (1 + ((variant & F_TEX) ? 6 : 2))) * sizeof(int) : 0);

@@ -24,6 +24,20 @@
 __device__ __forceinline__ int lane_rank(unsigned long long mask) {  // set bits below my lane
   return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
 }
+// Exclusive prefix sum of a small non-negative per-lane count over the wave's 64 lanes, in registers: four
+// row_shr steps inside each row of 16 lanes, then the two row broadcasts of the gfx9 DPP unit (row_bcast:15 into
+// rows 1 and 3, row_bcast:31 into rows 2 and 3).  Six add-with-DPP instructions in place of one ballot + mbcnt
+// pair per bit of the count.
+__device__ __forceinline__ int wave_prefix_excl(int v) {
+  int s = v;
+  s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, true);   // row_shr:1
+  s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, true);   // row_shr:2
+  s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, true);   // row_shr:4
+  s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, true);   // row_shr:8
+  s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return s - v;
+}
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();

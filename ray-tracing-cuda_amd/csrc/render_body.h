@@ -21,6 +21,8 @@ struct LaunchCfg {
   int32_t paths_off;   // byte offset of the staged leaf-path words
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
   int32_t priority;    // 1: the wave's issue priority follows the rank of the tiles it holds (needs tile_order)
+  int32_t nrm_off;     // byte offset of the staged TriNrm records (with pairs_off), -1: not staged
+  int32_t pad3;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *head_list;     // optional (with sparse_items): the head's items by weight class (SchedPlan::head_list)
   const uint32_t *probe_marks;   // with head_list: bit 31 of an item's word = it is in the head
@@ -53,12 +55,20 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.pair_pts);
     uint32_t *dst = reinterpret_cast<uint32_t *>(smem + lc.pairs_off);
     for (int w = threadIdx.x; w < sc.n_pairs * 16; w += blockDim.x) dst[w] = src[w];
+    const uint32_t *nsrc = reinterpret_cast<const uint32_t *>(sc.tri_nrm);
+    uint32_t *ndst = reinterpret_cast<uint32_t *>(smem + lc.nrm_off);
+    for (int w = threadIdx.x; w < sc.n_pairs * 8; w += blockDim.x) ndst[w] = nsrc[w];
   }
+  const float4 *s_nrm = reinterpret_cast<const float4 *>(smem + (lc.nrm_off >= 0 ? lc.nrm_off : 0));
   int *ll = nullptr;  // this wave's region for the shared candidate tests of the culled list scan
   if ((F & F_TRIS) && lc.list_off >= 0)
     ll = reinterpret_cast<int *>(smem + lc.list_off) +
          __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * 8 + kListTasks * (1 + ((F & F_TEX) ? 6 : 2)));
   const bool mats_in_lds = lc.lds_mats > 0;
+  auto lds_rgb = [&](int m) -> V3 {  // a staged material's colour: one 16-byte read (MatRec: r, g, b, kind)
+    const float4 c = *reinterpret_cast<const float4 *>(s_mats + m);
+    return mk(c.x, c.y, c.z);
+  };
   const bool fast_fold = mats_in_lds && lc.wide_ids != 1 && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
@@ -80,6 +90,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   const int64_t n_items = fr.items;
   const bool w_pow2 = (fr.width & (fr.width - 1)) == 0, h_pow2 = (fr.height & (fr.height - 1)) == 0;
   const double inv_w = 1.0 / (double)fr.width, inv_h = 1.0 / (double)fr.height;
+  const bool f32_jitter = w_pow2 && h_pow2 && fr.width <= (1 << 20) && fr.height <= (1 << 20);  // (wave-uniform)
   // per-lane pixel state
   int64_t q = 0;
   int pi = 0, pj = 0, k = 0;
@@ -148,7 +159,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     return true;
   };
 
-  RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();)
+  RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
+            const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
   for (;;) {
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
     // -------------------------------------------------------- sample / pixel bookkeeping
@@ -255,16 +267,29 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         // ray_tracing.cu:68-74 + camera.cu:57-70
         float r1 = rng_01(rng);
         float r2 = rng_01(rng);
-        // division by a power of two is an exact scaling: multiply by the (exact) reciprocal
-        double x = (double)r1 + (double)pj;
-        double y = (double)r2 + (double)(fr.height - pi);
-        x = w_pow2 ? x * inv_w : x / (double)fr.width;
-        y = h_pow2 ? y * inv_h : y / (double)fr.height;
-        x = 2 * x - 1;
-        y = 2 * y - 1;
-        x = (x + 1) / 2;
-        y = (y + 1) / 2;
-        V3 target = sc.cam.llc + (float)x * sc.cam.horizontal + (float)y * sc.cam.vertical;
+        // ray_tracing.cu:68-73 in binary64: x = (u + j) / W, then x = 2x - 1 and, inside RayAt, x = (x + 1) / 2.
+        float xf, yf;
+        if (f32_jitter) {
+          // Power-of-two frame: every binary64 step is EXACT -- u + j needs at most 24 + 13 bits, the division
+          // is a scaling, 2x - 1 and (x + 1) / 2 undo each other without rounding -- so the only rounding is the
+          // final (float)x of the exact (u + j) / W; and rounding commutes with a power-of-two scaling, so that
+          // is RN(u + j) * (1 / W): one binary32 addition (correctly rounded sum of two binary32 numbers) and an
+          // exact multiplication.  (tests/test_host_logic.py::test_jitter_in_binary32_for_power_of_two_frames)
+          xf = (r1 + (float)pj) * (float)inv_w;
+          yf = (r2 + (float)(fr.height - pi)) * (float)inv_h;
+        } else {
+          double x = (double)r1 + (double)pj;
+          double y = (double)r2 + (double)(fr.height - pi);
+          // division by a power of two is an exact scaling: multiply by the (exact) reciprocal
+          x = w_pow2 ? x * inv_w : x / (double)fr.width;
+          y = h_pow2 ? y * inv_h : y / (double)fr.height;
+          x = 2 * x - 1;
+          y = 2 * y - 1;
+          x = (x + 1) / 2;
+          y = (y + 1) / 2;
+          xf = (float)x, yf = (float)y;
+        }
+        V3 target = sc.cam.llc + xf * sc.cam.horizontal + yf * sc.cam.vertical;
         V3 origin = sc.cam.position;
         if (F & F_DEFOCUS) {
           if (sc.cam.defocus) {  // camera.cu:63-65,74-77 (a square, drawn left to right)
@@ -328,12 +353,19 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           int mat = 0;
           float tu = 0.f, tv = 0.f;  // record.u, record.v (only read by image textures)
           if ((F & F_TRIS) && kind == RUN_TRIS) {
-            const HotTri &tr = sc.tris[index];  // per-lane gather of the winner (L1/L2 resident)
-            V3 n = mk(tr.n[0], tr.n[1], tr.n[2]);
+            V3 n;
+            int flags;
+            if (s_pairs != nullptr) {  // (wave-uniform) the winner's record is in LDS
+              const float4 tn = s_nrm[index];
+              n = mk(tn.x, tn.y, tn.z);
+              mat = __float_as_int(tn.w) & 0xffffff, flags = __float_as_int(tn.w) >> 24;
+            } else {
+              const HotTri &tr = sc.tris[index];  // per-lane gather of the winner (L1/L2 resident)
+              n = mk(tr.n[0], tr.n[1], tr.n[2]);
+              mat = tr.mat, flags = tr.flags;
+            }
             nrm = dot3(d, n) < 0.f ? n : -n;  // utils.cu:80
-            mat = tr.mat;
             if (F & F_TEX) {
-              const int flags = tr.flags;
               if (flags & TRI_PGRAM) {  // parallelogram.cu:26-29,35-38
                 float w = (float)((1.0 - (double)h.u) - (double)h.v);
                 if (!(flags & TRI_SECOND)) {
@@ -456,15 +488,15 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           if (nibble_ids) {
             if (i >= 0 && !(i & 1)) {  // an even top level sits alone in the low half of its byte
               const int m0 = smem[ids_offset(i >> 1)] & 15;
-              result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+              { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
               i--;
             }
             for (; i >= 3; i -= 4) {  // i odd: bytes (i >> 1) and (i >> 1) - 1 hold levels i, i - 1 and i - 2, i - 3
               const uint32_t at = ids_offset(i >> 1);
               const uint32_t b0 = smem[at], b1 = smem[at - step];
               const int m0 = b0 >> 4, m1 = b0 & 15, m2 = b1 >> 4, m3 = b1 & 15;
-              const V3 a0 = mk(s_mats[m0].r, s_mats[m0].g, s_mats[m0].b), a1 = mk(s_mats[m1].r, s_mats[m1].g, s_mats[m1].b);
-              const V3 a2 = mk(s_mats[m2].r, s_mats[m2].g, s_mats[m2].b), a3 = mk(s_mats[m3].r, s_mats[m3].g, s_mats[m3].b);
+              const V3 a0 = lds_rgb(m0), a1 = lds_rgb(m1);
+              const V3 a2 = lds_rgb(m2), a3 = lds_rgb(m3);
               result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
               result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
               result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
@@ -473,15 +505,15 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
             for (; i >= 1; i -= 2) {
               const uint32_t b0 = smem[ids_offset(i >> 1)];
               const int m0 = b0 >> 4, m1 = b0 & 15;
-              result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
-              result = mk(s_mats[m1].r * result.x, s_mats[m1].g * result.y, s_mats[m1].b * result.z);
+              { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
+              { const V3 a_ = lds_rgb(m1); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
             }
           }
           for (; i >= 3; i -= 4) {
             const uint32_t at = ids_offset(i);
             const int m0 = smem[at], m1 = smem[at - step], m2 = smem[at - 2u * step], m3 = smem[at - 3u * step];
-            const V3 a0 = mk(s_mats[m0].r, s_mats[m0].g, s_mats[m0].b), a1 = mk(s_mats[m1].r, s_mats[m1].g, s_mats[m1].b);
-            const V3 a2 = mk(s_mats[m2].r, s_mats[m2].g, s_mats[m2].b), a3 = mk(s_mats[m3].r, s_mats[m3].g, s_mats[m3].b);
+            const V3 a0 = lds_rgb(m0), a1 = lds_rgb(m1);
+            const V3 a2 = lds_rgb(m2), a3 = lds_rgb(m3);
             result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
             result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
             result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
@@ -489,7 +521,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           }
           for (; i >= 0; i--) {
             const int m0 = smem[ids_offset(i)];
-            result = mk(s_mats[m0].r * result.x, s_mats[m0].g * result.y, s_mats[m0].b * result.z);
+            { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
           }
         }
         for (; i >= 0; i--) {
@@ -501,7 +533,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                            : lc.wide_ids ? (int)*reinterpret_cast<const uint16_t *>(smem + ids_offset(i))
                                          : (int)smem[ids_offset(i)];
             if (mats_in_lds) {
-              a = mk(s_mats[mi].r, s_mats[mi].g, s_mats[mi].b);
+              a = lds_rgb(mi);
             } else {
               a = mk(sc.mats[mi].r, sc.mats[mi].g, sc.mats[mi].b);
             }
@@ -542,6 +574,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       atomicAdd(&counters[25], g_wave_stats[wid][9]);
       atomicAdd(&counters[6], g_wave_stats[wid][10]);
       g_wave_stats[wid][9] = 0, g_wave_stats[wid][10] = 0;
+      // per wave (tools/gpu_shard_waves.py): lifetime in shader cycles, queries, start and end on the 100 MHz clock
+      g_wave_stats[wid][0] = life, g_wave_stats[wid][11] = wave_queries;
+      g_wave_stats[wid][12] = t_begin_rt, g_wave_stats[wid][13] = __builtin_amdgcn_s_memrealtime();
     } else if (wid < 16384u) {
       g_wave_stats[wid][0] = life;
 #if RTMI_STATS != 9

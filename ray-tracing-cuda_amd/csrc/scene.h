@@ -63,6 +63,7 @@ struct Scene {
   std::vector<HotTri> tris;
   std::vector<PairBox> pair_boxes;
   std::vector<PairPts> pair_pts;
+  std::vector<TriNrm> tri_nrm;
   float list_mag = 0.f;
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;

@@ -466,7 +466,7 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
 }
 
 std::string Scene::flatten() {
-  pair_boxes.clear(), pair_pts.clear(), list_mag = 0.f;
+  pair_boxes.clear(), pair_pts.clear(), tri_nrm.clear(), list_mag = 0.f;
   runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(), tops.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
@@ -662,6 +662,12 @@ std::string Scene::flatten() {
   if (!face_uv.empty()) face_uv.resize(faces.size() * 6, 0.f);
   if (!faces.empty())  // the kernel fetches sub-leaf faces four at a time
     for (int i = 0; i < 4; i++) faces.push_back(FaceRec{});
+  for (size_t t = 0; t < 2 * pair_pts.size() && t < tris.size(); t++) {
+    TriNrm r{};
+    for (int c = 0; c < 3; c++) r.n[c] = tris[t].n[c];
+    r.mat_flags = (tris[t].mat & 0xffffff) | (tris[t].flags << 24);
+    tri_nrm.push_back(r);
+  }
   if (!tris.empty()) {  // prefetch target past the last pair (fetched, never tested)
     tris.push_back(HotTri{});
     tris.push_back(HotTri{});

@@ -70,15 +70,22 @@ struct alignas(16) PairPts {  // 64 B
   int32_t flags;
   int32_t pad[3];
 };
+// What shading needs of the winning world-list triangle, staged in LDS next to the pairs (one record per
+// HotTri, same index): the unit normal and the material (low 24 bits) | HotTri::flags << 24.  A per-lane read
+// of 16 bytes from LDS instead of a 64-byte gather from global memory on every hit.
+struct alignas(16) TriNrm {
+  float n[3];
+  int32_t mat_flags;
+};
 constexpr int kCullMinPairs = 4;  // shorter lists are scanned plainly: the cull and the hand-over through LDS cost more than they save
 constexpr int kListTasks = 192;  // (ray, pair) tasks of the culled list scan that one wave holds in LDS at a time
 constexpr int kLdsPairs = 128;  // at most this many PairPts records are staged in LDS (8 KiB); longer lists use the plain scan
 
 enum MatKind : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_SKY = 4 };
 
-struct MatRec {  // 32 B
-  int32_t kind;
+struct alignas(16) MatRec {  // 32 B; colour + kind are one 16-byte LDS read
   float r, g, b;   // constant albedo / attenuation / emission
+  int32_t kind;
   float param;     // Metal: fuzz (already min(fuzz,1)); Dielectric: (float)refractive_index
   int32_t tex;     // >= 0: image texture supplies the colour instead of r,g,b
   int32_t pad[2];
@@ -179,6 +186,7 @@ struct SceneDev {
   const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
   const PairBox *pair_boxes;  // per pair of `tris` records (index = tri index / 2), one inert record of padding
   const PairPts *pair_pts;
+  const TriNrm *tri_nrm;      // per `tris` record (2 * n_pairs), staged in LDS with pair_pts
   const BvhRec *bvhs;
   const BvhNode *nodes;
   const QNode4 *qnodes;

@@ -106,6 +106,12 @@ __device__ __forceinline__ bool tri_test_flat(V3 p0, V3 e1, V3 e2, V3 pvec, V3 o
   return ok;
 }
 
+// mask = 2 * mask + (a <= b): the compare writes the lane's verdict to VCC and the add takes it as its carry-in --
+// two instructions where the compiler's select / or takes four (a VOP3 reads one SGPR at most on gfx9).
+__device__ __forceinline__ void cull_step(uint32_t &mask, float a, float b) {
+  asm("v_cmp_le_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
+}
+
 // World-list triangle records are read through the constant address space: a
 // wave-uniform address there always selects scalar loads (one s_load_dwordx16 per
 // record into SGPRs) instead of per-lane vector loads.

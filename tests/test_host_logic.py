@@ -52,6 +52,28 @@ def test_rejection_threshold():
     assert float(thr) == 1.00000011920928955078125
 
 
+def test_jitter_in_binary32_for_power_of_two_frames():
+    """render_body.h forms the pixel jitter of ray_tracing.cu:68-73 (binary64: (u + j) / W, 2x - 1, then (x + 1) / 2
+    in Camera::RayAt, camera.cu:58-59, and a final float cast) as RN32(u + j) * (1 / W) when W is a power of two: check
+    the two against each other on every shape of uniform variate (tiny, mid-range, 1.0) and every column."""
+    f32, f64 = np.float32, np.float64
+    rng = np.random.default_rng(5)
+    draws = np.concatenate([rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint64), np.arange(0, 4096, dtype=np.uint64),
+                            2 ** 32 - 1 - np.arange(0, 4096, dtype=np.uint64),
+                            (np.uint64(1) << np.arange(0, 32, dtype=np.uint64))]).astype(np.uint32)
+    # curand_uniform (utils.cuh:22-27 over XORWOW): x * 2^-32 + 2^-33 in binary32
+    u = (draws.astype(f32) * f32(2.3283064e-10) + f32(1.16415322e-10)).astype(f32)
+    assert u.min() > 0 and u.max() == 1.0
+    for W in (1, 8, 256, 1024, 4096, 1 << 20):
+        j = rng.integers(0, W + 1, u.size).astype(np.int64)  # columns 0..W-1, and H - i reaches H
+        x = (u.astype(f64) + j.astype(f64)) / f64(W)
+        x = 2 * x - 1
+        x = (x + 1) / 2
+        ref = x.astype(f32)
+        got = ((u + j.astype(f32)).astype(f32) * f32(1.0 / W)).astype(f32)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), W
+
+
 @pytest.mark.parametrize("h,w", [(8, 8), (20, 30), (37, 53), (64, 64), (1, 1), (9, 200)])
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
 def test_tile_shards_partition_the_frame(h, w, world):
