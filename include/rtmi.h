@@ -230,8 +230,13 @@ int rtmi_get_workload(int rank, int world_size, int spp);
  *  [1] differing inputs outside that range, where the kernels divide (informative, > 0);
  *  [2] CudaRandomFloat(-1, 1) (utils.cuh:22-27) as fma(x, 2^-31, 2^-32) - 1: draws x that differ
  *      from curand_uniform(x) * (1 - -1) + -1 -- must be 0;
- *  [3] CudaRandomFloat(0, 1) as fma(x, 2^-32, 2^-33) -- must be 0. */
-int rtmi_selftest_arithmetic(unsigned long long mismatches[4]);
+ *  [3] CudaRandomFloat(0, 1) as fma(x, 2^-32, 2^-33) -- must be 0;
+ *  [4] sqrtf(x) (glm::normalize's sqrt, ray.cu:10; lambertian.cu:25) as reciprocal square root + one FMA correction,
+ *      on every binary32 in [2^-100, 2^100) -- must be 0;
+ *  [5] the Lambertian sampler's `vec /= l` (lambertian.cu:29) as one correctly rounded reciprocal + two FMA
+ *      corrections per coordinate, on 2^32 triples of sampler draws -- must be 0;
+ *  [6] the same with one correction only (informative);  [7] unused. */
+int rtmi_selftest_arithmetic(unsigned long long mismatches[8]);
 
 /* Per-call scheduling options of rtmi_render_ex.  The reference fixes its launch shape at compile
  * time (dim3(8,8) blocks, utils.cu:158); here the shape and the work-queue order are run-time

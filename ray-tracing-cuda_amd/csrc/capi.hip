@@ -405,6 +405,12 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.n_nodes = (int)s->nodes.size();
   d.n_leaf_paths = (int)s->leaf_paths.size();
   d.sub_reserve = s->sub_depth > 0 ? 3 * s->sub_depth + 3 + kMeshFaceSlack : 0;
+  d.det_safe = 1;
+  for (const HotTri &t : s->tris) {
+    const double a = std::sqrt((double)t.e1[0] * t.e1[0] + (double)t.e1[1] * t.e1[1] + (double)t.e1[2] * t.e1[2]);
+    const double b = std::sqrt((double)t.e2[0] * t.e2[0] + (double)t.e2[1] * t.e2[1] + (double)t.e2[2] * t.e2[2]);
+    if (!(a * b <= 0x1p120)) d.det_safe = 0;
+  }
   d.unsigned_colours = 1;
   for (const MatRec &m : s->mat_recs) {
     const float c[3] = {m.r, m.g, m.b};
@@ -756,6 +762,7 @@ int rtmi_debug_wave_stats(unsigned long long *out, size_t bytes) {
 // RCCL is not a link-time dependency of this library: the caller owns the communicator, so its RCCL is already
 // in the process (a second copy must not be pulled in next to e.g. the one PyTorch bundles).  The four entry points
 // are taken from the process image, or from librccl.so.1 when nothing has loaded it yet.
+extern "C++" {
 namespace {
 struct Rccl {
   decltype(&ncclGroupStart) group_start = nullptr;
@@ -788,6 +795,7 @@ int rccl_fail(const Rccl &R, ncclResult_t e, const char *what) {
   return fail(RTMI_ERR_HIP, std::string(what) + ": " + (R.err ? R.err(e) : "RCCL error"));
 }
 }  // namespace
+}  // extern "C++"
 #define RCCL_TRY(expr)                                        \
   do {                                                        \
     ncclResult_t e__ = (expr);                                \
@@ -854,10 +862,10 @@ int rtmi_selftest_arithmetic(unsigned long long *mismatches) {
   if (!mismatches) return fail(RTMI_ERR_INVALID, "mismatches == NULL");
   if (rtmi_device_count() <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device: librtmi has no CPU fallback");
   unsigned long long *d_bad = nullptr;
-  HIP_TRY(hipMalloc(&d_bad, 4 * sizeof(unsigned long long)));
-  hipError_t e = hipMemset(d_bad, 0, 4 * sizeof(unsigned long long));
+  HIP_TRY(hipMalloc(&d_bad, 8 * sizeof(unsigned long long)));
+  hipError_t e = hipMemset(d_bad, 0, 8 * sizeof(unsigned long long));
   if (e == hipSuccess) e = launch_arithmetic_selftest(d_bad, nullptr);
-  if (e == hipSuccess) e = hipMemcpy(mismatches, d_bad, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(mismatches, d_bad, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   (void)hipFree(d_bad);
   HIP_TRY(e);
   return RTMI_OK;

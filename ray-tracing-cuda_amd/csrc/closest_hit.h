@@ -35,6 +35,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   }
 
   const int lane = (int)(threadIdx.x & 63u);
+  const bool det_safe = sc.det_safe != 0;  // (a kernel argument: the branch on it waits for no vector result)
   // the ray as the culled list scan wants it: 1/d (the hardware reciprocal will do: the test is conservative by
   // a margin of 1e-5, not 1e-7), and -(o +- delta)/d per axis, delta = the distance slack of the mesh search
   V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
@@ -171,11 +172,11 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                 const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
                 float ta = 0.f, ua = 0.f, va = 0.f, tb = 0.f, ub = 0.f, vb = 0.f;
                 const V3 e1 = p1 - p0, e2 = p2 - p0;  // utils.cu:54-55, the subtractions scene.hip: make_tri does
-                const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(rd, e2), ro, rd, t0_to, ta, ua, va);
+                const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(rd, e2), ro, rd, t0_to, ta, ua, va, det_safe);
                 bool hit_b = false;
                 if (__float_as_int(qd.x) & PAIR_SECOND) {
                   const V3 e1b = p2 - p1, e2b = p3 - p1;
-                  hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(rd, e2b), ro, rd, t0_to, tb, ub, vb);
+                  hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(rd, e2b), ro, rd, t0_to, tb, ub, vb, det_safe);
                 }
                 int *res = results + ti * RW;
                 res[0] = hit_a ? __float_as_int(ta) : (int)0xffffffff;  // (a NaN pattern no t can have)
@@ -232,7 +233,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         float t = 0.f, u = 0.f, v = 0.f;
         const V3 pv_a = cross3(d, mk(A[6], A[7], A[8]));
         const bool hit_a = tri_test_flat<T>(mk(A[0], A[1], A[2]), mk(A[3], A[4], A[5]), mk(A[6], A[7], A[8]), pv_a, o, d,
-                                            t_to, t, u, v);
+                                            t_to, t, u, v, det_safe);
         {
           bool acc = hit_a && (!ok || (T)t < t_to);
           ok = ok || acc;
@@ -252,7 +253,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           V3 pv_b = pv_a;
           if (!(__float_as_int(B[13]) & TRI_SAME_E2)) pv_b = cross3(d, mk(B[6], B[7], B[8]));  // wave-uniform
           bool hit_b = tri_test_flat<T>(mk(B[0], B[1], B[2]), mk(B[3], B[4], B[5]), mk(B[6], B[7], B[8]), pv_b, o, d,
-                                        t_to, t, u, v);
+                                        t_to, t, u, v, det_safe);
           hit_b = hit_b && !hit_a;
           bool acc = hit_b && (!ok || (T)t < t_to);
           ok = ok || acc;

@@ -336,13 +336,22 @@ hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_co
 // Runs every shortened operation against the expression it replaces on all 2^32 inputs:
 // bad[0] rcp_rn(x) vs 1.0f / x inside rcp_rn's domain (must be 0), bad[1] outside it
 // (informative), bad[2] rng_pm1_of(x) vs the reference's uniform(-1, 1) expression, bad[3]
-// rng_01_of(x) vs uniform(0, 1) (both must be 0).
+// rng_01_of(x) vs uniform(0, 1) (both must be 0), bad[4] sqrt_rn_core(x) vs sqrtf(x) on its domain (must be 0),
+// bad[5] div_rn_core vs a / l on 2^32 triples of sampler draws (must be 0), bad[6] the same with a single
+// correction (informative).
 __device__ __forceinline__ float ref_uniform(uint32_t x) { return (float)x * 2.3283064e-10f + 1.16415322e-10f; }
 __device__ __forceinline__ float ref_range(float mn, float mx, uint32_t x) { return ref_uniform(x) * (mx - mn) + mn; }
+__device__ __forceinline__ uint32_t selftest_mix(uint64_t &s) {  // splitmix64
+  s += 0x9e3779b97f4a7c15ull;
+  uint64_t z = s;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
 __global__ __launch_bounds__(256) void arithmetic_selftest(unsigned long long *bad, float mn1, float mx1, float mn0,
                                                            float mx0) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  unsigned long long in_domain = 0, outside = 0, pm1 = 0, u01 = 0;
+  unsigned long long in_domain = 0, outside = 0, pm1 = 0, u01 = 0, sq = 0, dv = 0, dv1 = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
     const uint32_t bits = (uint32_t)i;
     const float x = __uint_as_float(bits);
@@ -356,11 +365,40 @@ __global__ __launch_bounds__(256) void arithmetic_selftest(unsigned long long *b
     // evaluated operation by operation, not folded at compile time
     if (__float_as_uint(ref_range(mn1, mx1, bits)) != __float_as_uint(rng_pm1_of(bits))) pm1++;
     if (__float_as_uint(ref_range(mn0, mx0, bits)) != __float_as_uint(rng_01_of(bits))) u01++;
+    // sqrt_rn_core against sqrtf on its whole domain
+    if (x >= SQRT_RN_LO && x < SQRT_RN_HI && __float_as_uint(sqrtf(x)) != __float_as_uint(sqrt_rn_core(x))) sq++;
+  }
+  // div_rn_core against the division on the Lambertian sampler's own operands (lambertian.cu:19-31): 2^32 triples
+  // of draws, every eighth shrunk towards the corner (-1, -1, -1), every eighth towards the origin (tiny lengths)
+  uint64_t st = 0x1234567ull + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 0x632be59bd9b4e019ull;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+    uint32_t rx = selftest_mix(st), ry = selftest_mix(st), rz = selftest_mix(st);
+    const uint32_t sh = selftest_mix(st);
+    if ((i & 7) == 0) rx >>= (sh & 31), ry >>= ((sh >> 5) & 31), rz >>= ((sh >> 10) & 31);
+    if ((i & 7) == 1)
+      rx = 0x80000000u + (rx >> (8 + (sh & 15))), ry = 0x80000000u - (ry >> (8 + ((sh >> 4) & 15))),
+      rz = 0x80000000u + (rz >> (8 + ((sh >> 8) & 15)));
+    const float cx = rng_pm1_of(rx), cy = rng_pm1_of(ry), cz = rng_pm1_of(rz);
+    const float sum = cx * cx + cy * cy + cz * cz;
+    if (sum > BALL_S_MAX) continue;
+    const float l = sqrtf(sum);
+    if (!(l >= DIV3_RN_LO)) continue;
+    const float y = rcp_rn(l);
+    const float v[3] = {cx, cy, cz};
+    for (int k = 0; k < 3; k++) {
+      const float ref = v[k] / l;
+      const float q0 = v[k] * y;
+      if (__float_as_uint(ref) != __float_as_uint(div_rn_core(v[k], l, y))) dv++;
+      if (__float_as_uint(ref) != __float_as_uint(__builtin_fmaf(__builtin_fmaf(-l, q0, v[k]), y, q0))) dv1++;
+    }
   }
   if (in_domain) atomicAdd(&bad[0], in_domain);
   if (outside) atomicAdd(&bad[1], outside);
   if (pm1) atomicAdd(&bad[2], pm1);
   if (u01) atomicAdd(&bad[3], u01);
+  if (sq) atomicAdd(&bad[4], sq);
+  if (dv) atomicAdd(&bad[5], dv);
+  if (dv1) atomicAdd(&bad[6], dv1);
 }
 #ifdef RTMI_STATS
 hipError_t copy_wave_stats(unsigned long long *host, size_t bytes) {

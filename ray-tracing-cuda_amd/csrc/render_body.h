@@ -299,7 +299,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           }
         }
         o = origin;
-        d = unit3_rn(unit3_rn(target - origin));  // RayAt normalises, Ray's constructor normalises again
+        d = unit3_rn_twice(target - origin);  // RayAt normalises, Ray's constructor normalises again
         k++;
         depth = 0;
         active = true;
@@ -426,9 +426,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               if (!(dn >= 0.f)) {
                 float sum;
                 V3 s = ball_sample(rng, sum);
-                const float l = sqrtf(sum);
-                s = mk(s.x / l, s.y / l, s.z / l);
-                nd = unit3_rn(s + nrm);
+                s = sampler_on_sphere(s, sum);  // l = (float)pow((double)sum, 0.5); vec /= l (lambertian.cu:25-29)
+                nd = unit3_rn_twice(s + nrm);   // normalize(S + n), then Ray's constructor (lambertian.cu:41-42)
                 scattered = true;
               }
             } else if (m.kind == MAT_METAL) {  // metal.cu:12-25
@@ -441,6 +440,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
                 } else {
                   nd = refl;
                 }
+                nd = unit3_rn(nd);  // Ray's constructor
                 scattered = true;
               }
             } else {  // MAT_DIELECTRIC, dielectric.cu:16-44
@@ -451,6 +451,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               bool zero = (nd.x == 0.f && nd.y == 0.f && nd.z == 0.f);
               bool nan = (nd.x != nd.x) || (nd.y != nd.y) || (nd.z != nd.z);
               scattered = !(zero || nan);
+              if (scattered) nd = unit3_rn(nd);  // Ray's constructor
             }
             if (scattered) {
               if (F & F_TEX) {
@@ -468,7 +469,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               }
               depth++;
               o = p;
-              d = unit3_rn(nd);  // Ray's constructor
+              d = nd;  // (normalised by Ray's constructor in its material's branch above)
               ended = false;
             }
           }

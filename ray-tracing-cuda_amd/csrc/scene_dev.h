@@ -203,6 +203,9 @@ struct SceneDev {
   float list_mag;     // largest |coordinate| of the world-list triangles (scales the cull's distance slack)
   int32_t sub_reserve;  // 3 * (deepest search tree) + 3 + kMeshFaceSlack: stack words the wave-wide search keeps free
                         // after a wide step (0 without meshes); see mesh_search
+  int32_t det_safe;   // 1: |e1| * |e2| <= 2^120 for every world-list triangle, so that the Moller-Trumbore determinant
+                      // e1 . (d x e2) of a unit (or NaN) direction stays below rcp_rn's limit 2^126 and the list scan
+                      // needs no run-time check in front of its reciprocal (tri_test_flat)
   int32_t unsigned_colours;  // 1: no material colour has its sign bit set (not even -0): then every layer
                              // product is +0, positive or NaN and `emitted(0) + product` is the product itself
   CameraDev cam;

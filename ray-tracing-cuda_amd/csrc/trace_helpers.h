@@ -38,18 +38,105 @@ __device__ __forceinline__ float rcp_rn(float x) {
   return __builtin_fmaf(e, r, r);
 }
 
+// Correctly rounded sqrt(x) in five instructions for 2^-100 <= x < 2^100: the hardware reciprocal square root
+// (within 1 ulp), g = x * y and h = y / 2, and one correction on the exact FMA residual x - g * g.  Like rcp_rn this
+// is established by exhaustion: arithmetic_selftest compares it with sqrtf on every binary32 of that range (1.68e9
+// inputs, mismatches[4]; hipcc's own correctly rounded sqrtf is a 16-instruction sequence).  Outside the range
+// (zero, denormal, huge, inf, NaN, negative) callers use sqrtf.
+#define SQRT_RN_LO 0x1p-100f
+#define SQRT_RN_HI 0x1p100f
+__device__ __forceinline__ float sqrt_rn_core(float x) {
+  const float y = __builtin_amdgcn_rsqf(x);
+  const float g = x * y, h = 0.5f * y;
+  const float d = __builtin_fmaf(-g, g, x);
+  return __builtin_fmaf(d, h, g);
+}
+// sqrtf(x), wave-cooperative: the short form when every lane's operand is inside its domain.
+#ifndef RTMI_OPT_SQRT
+#define RTMI_OPT_SQRT 1
+#endif
+#ifndef RTMI_OPT_DIV3
+#define RTMI_OPT_DIV3 1
+#endif
+__device__ __forceinline__ float sqrt_rn(float x) {
+#if RTMI_OPT_SQRT
+  if (__all(x >= SQRT_RN_LO && x < SQRT_RN_HI)) return sqrt_rn_core(x);
+#endif
+  return sqrtf(x);
+}
+
+// a / b for the three coordinates of a vector and one divisor, correctly rounded, without the 11-instruction IEEE
+// sequence per quotient: y = RN(1 / b) (rcp_rn, exact by exhaustion), q0 = RN(a * y), and two corrections
+// q <- RN(q + RN(a - b * q) * y) on the exact FMA residual.  q0 is within 1.5 ulp of a / b, the first correction
+// brings it within (1/2 + 2^-23) ulp -- a faithful rounding -- and for a faithful q and a correctly rounded
+// reciprocal the corrected value IS the correctly rounded quotient (Markstein's theorem); no residual underflows
+// for a == 0 or |a| >= 2^-40, 2^-40 <= b <= 2 (the caller's operands: sampler coordinates, multiples of 2^-24,
+// over their own length).  arithmetic_selftest runs it against the division on 2^32 sampler operand triples
+// (mismatches[5], and [6] counts what a single correction would get wrong: 0 of 1e11 in tools/exp).
+#define DIV3_RN_LO 0x1p-40f
+__device__ __forceinline__ float div_rn_core(float a, float b, float y) {
+  float q = a * y;
+  q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+  q = __builtin_fmaf(__builtin_fmaf(-b, q, a), y, q);
+  return q;
+}
+// lambertian.cu:25-29: l = sqrt(sum), vec /= l for a point (x, y, z) of the sampler -- coordinates that are
+// multiples of 2^-24 in [-1, 1] (rng_pm1_of), sum = x*x + y*y + z*z <= 1 + 2^-23.  One wave-uniform domain check for
+// the square root and the three quotients: sum >= 2^-80 (false only for the point (0, 0, 0), probability 2^-72,
+// which takes the IEEE forms with the rest of its wave); then l >= 2^-40 and every nonzero |coordinate| >= 2^-24.
+__device__ __forceinline__ V3 sampler_on_sphere(V3 a, float sum) {
+#if RTMI_OPT_DIV3
+  if (__all(sum >= 0x1p-80f)) {
+    const float l = sqrt_rn_core(sum);
+    const float y = rcp_rn(l);
+    return mk(div_rn_core(a.x, l, y), div_rn_core(a.y, l, y), div_rn_core(a.z, l, y));
+  }
+  const float l = sqrtf(sum);
+#else
+  const float l = sqrt_rn(sum);
+#endif
+  return mk(a.x / l, a.y / l, a.z / l);
+}
+
 // glm::normalize = v * (1 / sqrt(v.v)) (vec.h: unit3) with the reciprocal taken by rcp_rn: a
 // positive normal square root always lies inside rcp_rn's domain (2^-75 < sqrt(x) < 2^64); a
 // zero, NaN or infinite one sends the whole wave through the division.
 __device__ __forceinline__ V3 unit3_rn(V3 v) {
-  const float s = sqrtf(dot3(v, v));
+  const float dd = dot3(v, v);
   float inv;
+#if RTMI_OPT_SQRT
+  // one wave-uniform check for both short forms: 2^-100 <= v.v < 2^100 puts the square root inside rcp_rn's domain
+  if (__all(dd >= SQRT_RN_LO && dd < SQRT_RN_HI)) {
+    inv = rcp_rn(sqrt_rn_core(dd));
+  } else {
+    inv = 1.0f / sqrtf(dd);
+  }
+#else
+  const float s = sqrtf(dd);
   if (__all(__builtin_amdgcn_class(s, 0x100))) {  // +normal
     inv = rcp_rn(s);
   } else {
     inv = 1.0f / s;
   }
+#endif
   return v * inv;
+}
+
+// normalize(normalize(v)) -- Camera::RayAt then Ray's constructor (camera.cu:69, ray.cu:10), Lambertian::Scatter
+// then Ray's constructor (lambertian.cu:41-42) -- with ONE domain check: when v.v passes it the first result has
+// 1 - 2^-22 < u.u < 1 + 2^-22, which is inside both short forms' domains.
+__device__ __forceinline__ V3 unit3_rn_twice(V3 v) {
+#if RTMI_OPT_SQRT
+  const float dd = dot3(v, v);
+  if (__all(dd >= SQRT_RN_LO && dd < SQRT_RN_HI)) {
+    const V3 u = v * rcp_rn(sqrt_rn_core(dd));
+    return u * rcp_rn(sqrt_rn_core(dot3(u, u)));
+  }
+  const V3 u = v * (1.0f / sqrtf(dd));
+  return u * (1.0f / sqrtf(dot3(u, u)));
+#else
+  return unit3_rn(unit3_rn(v));
+#endif
 }
 
 // utils.cu:49-85 with the ray-independent terms precomputed.
@@ -81,16 +168,19 @@ __device__ __forceinline__ bool tri_test(V3 p0, V3 e1, V3 e2, V3 o, V3 d, T t_to
 // `pvec` = cross(d, e2) is passed in: a parallelogram's second triangle (p1,p2,p3) has the same
 // e2 = p3 - p1 = p2 - p0 as the first whenever the corner arithmetic was exact (TRI_SAME_E2,
 // decided on the host by comparing bit patterns) and then reuses the first one's product.
+// `det_safe` (wave-uniform, SceneDev::det_safe): the scene's edges bound |det| below rcp_rn's limit for every
+// unit direction, so no lane can need the division (a NaN direction gives NaN either way) and the wave-wide
+// check -- a vector compare the scalar branch has to wait for -- is skipped.
 template <typename T>
 __device__ __forceinline__ bool tri_test_flat(V3 p0, V3 e1, V3 e2, V3 pvec, V3 o, V3 d, T t_to, float &t, float &u,
-                                              float &v) {
+                                              float &v, bool det_safe = false) {
   float det = dot3(e1, pvec);
   bool ok = !(fabsf(det) < DET_EPS_F);
   // 1.0f / det (utils.cu:59).  Lanes with |det| < 1e-7 have ok == false and never look at inv;
   // for the others rcp_rn is the IEEE quotient unless some |det| >= 2^126 (or NaN), in which
   // case the whole wave divides.
   float inv;
-  if (__all(fabsf(det) < RCP_RN_LIMIT)) {
+  if (det_safe || __all(fabsf(det) < RCP_RN_LIMIT)) {
     inv = rcp_rn(det);
   } else {
     inv = 1.0f / det;

@@ -246,7 +246,9 @@ def test_shortened_arithmetic_equals_the_reference_expressions_on_this_device():
     each, zero differences (for the reciprocal: inside its stated domain)."""
     import ctypes as C
     import rtmi
-    bad = (C.c_ulonglong * 4)()
+    bad = (C.c_ulonglong * 8)()
     assert rtmi.lib().rtmi_selftest_arithmetic(bad) == 0
     assert bad[0] == 0 and bad[2] == 0 and bad[3] == 0, list(bad)
+    assert bad[4] == 0, "sqrt_rn differs from sqrtf on %d inputs of its domain" % bad[4]
+    assert bad[5] == 0, "div3_rn differs from the division on %d sampler operands" % bad[5]
     assert bad[1] > 0  # outside the domain (denormals, |x| >= 2^126) the reciprocal does differ: the kernels divide there
