@@ -67,7 +67,7 @@ def parse(argv=None):
     ap.add_argument("--shard", default=None, help="r/G: render shard r of a G-rank frame on this one GPU")
     ap.add_argument("--shard-sweep", type=int, default=0, metavar="G",
                     help="full frame, then each of the G shards, on this one GPU: predicted G-GPU speedup")
-    ap.add_argument("--priority", type=int, default=-1, help="rtmi_render_opts.priority (-1: library default)")
+    ap.add_argument("--probe-spp", type=int, default=0, help="rtmi_render_opts.probe_spp (0: library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--selftest-exchange", action="store_true",
@@ -239,7 +239,7 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
     R = rtmi.Renderer(scene, H, W, w["spp"], w["depth"], True, rank=r_rank, world_size=r_world)
     R.init_rng()
     pristine = R.states.clone()
-    opts = rtmi.render_opts(priority=args.priority) if args.priority >= 0 else None
+    opts = rtmi.render_opts(probe_spp=args.probe_spp) if args.probe_spp > 0 else None
     shape = R.launch_shape(opts)
     torch.cuda.synchronize()
 

@@ -260,8 +260,7 @@ typedef struct rtmi_render_opts {
                               * they render too */
   int32_t outlier_x10;       /* 0 default (20); with sparse_stride > 0: a tile is an outlier from this many tenths of
                               * the mean tile cost */
-  int32_t priority;          /* -1 default; 1: a wave's issue priority follows the rank of the tiles it holds in the
-                              * longest-first order (the frame's longest chains run ahead of the bulk); 0: off */
+  int32_t probe_spp;         /* 0 default (2): samples per pixel of the scheduler's cost probe, 1..64 */
   int32_t head_pct[3];       /* 0 default (80, 55, 30): mesh frames, per cent of the frame's largest probe count from
                               * which a pixel gets a wave to itself / shares one with another / gets one lane in 16 */
   int32_t reserved;
@@ -284,7 +283,7 @@ int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_o
 
 /* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
- * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PRIORITY environment variables override the
+ * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PROBE_SPP environment variables override the
  * built-in defaults of those fields and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);

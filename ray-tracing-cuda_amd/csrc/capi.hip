@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>  // types and enumerators only: the entry points are looked up at run time (rtmi_gather)
 #include <string.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
@@ -55,7 +56,8 @@ static RenderTuning default_tuning() {
     g_tune.outlier_x10 = env_int("RTMI_OUTLIER_X10", 20);
     if (g_tune.outlier_x10 < 1) g_tune.outlier_x10 = 20;
     g_tune.head_pct[0] = 80, g_tune.head_pct[1] = 55, g_tune.head_pct[2] = 30;
-    g_tune.priority = env_int("RTMI_PRIORITY", 0) ? 1 : 0;
+    g_tune.probe_spp = env_int("RTMI_PROBE_SPP", 0);
+    if (g_tune.probe_spp < 0 || g_tune.probe_spp > 64) g_tune.probe_spp = 0;
   });
   std::lock_guard<std::mutex> lk(g_tune_mu);
   return g_tune;
@@ -562,7 +564,7 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
   if (opts->size != (int32_t)sizeof(rtmi_render_opts)) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.size does not match this library");
   if (opts->schedule > 2 || opts->blocks_per_cu < 0 || opts->threads_per_block < 0 || (opts->threads_per_block % 64) != 0 ||
       opts->threads_per_block > 512 || (opts->sparse_stride != 0 && !valid_stride(opts->sparse_stride)) || opts->exclusive > 1 ||
-      opts->outlier_x10 < 0 || opts->priority > 1)
+      opts->outlier_x10 < 0 || opts->probe_spp < 0 || opts->probe_spp > 64)
     return fail(RTMI_ERR_INVALID, "rtmi_render_opts field out of range");
   for (int i = 0; i < 3; i++)
     if (opts->head_pct[i] < 0 || opts->head_pct[i] > 100) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.head_pct outside [0, 100]");
@@ -572,7 +574,7 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
   if (opts->sparse_stride > 0) tune->sparse_stride = opts->sparse_stride;
   if (opts->exclusive >= 0) tune->exclusive = opts->exclusive;
   if (opts->outlier_x10 > 0) tune->outlier_x10 = opts->outlier_x10;
-  if (opts->priority >= 0) tune->priority = opts->priority;
+  if (opts->probe_spp > 0) tune->probe_spp = opts->probe_spp;
   for (int i = 0; i < 3; i++)
     if (opts->head_pct[i] > 0) tune->head_pct[i] = opts->head_pct[i];
   if (!(tune->head_pct[0] >= tune->head_pct[1] && tune->head_pct[1] >= tune->head_pct[2]))
@@ -669,8 +671,12 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
   SchedPlan plan;
-  const int probe_spp = 2;
-  const bool many_tiles = (int64_t)d.local_tiles * 64 > (int64_t)blocks * threads;
+  // Samples per pixel of the cost probe: two.  (More do not help, not even with 1.33 pixels per lane -- a 2048^2
+  // frame over eight GPUs -- where one might expect a mis-ranked heavy tile to matter: 2 / 4 / 8 / 16 spp give 606 /
+  // 620 / 609 / 614 ms on a C4 shard.  rtmi_render_opts.probe_spp keeps it adjustable.)
+  const int64_t resident = (int64_t)blocks * threads;
+  const int probe_spp = tune.probe_spp > 0 ? tune.probe_spp : 2;
+  const bool many_tiles = (int64_t)d.local_tiles * 64 > resident;
   if (tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
     const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
     void *scratch = user_scratch;

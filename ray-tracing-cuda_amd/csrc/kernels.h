@@ -32,7 +32,7 @@ struct RenderTuning {
   int outlier_x10;    // a tile is an outlier from this many tenths of the mean tile cost
   int head_pct[3];    // mesh frames: per cent of the frame's largest probe count from which a pixel gets a wave to itself,
                       // shares one with another, gets one lane in 16 (80 / 55 / 30)
-  int priority;       // 1: waves raise their issue priority with the rank of the tiles they hold in the longest-first order
+  int probe_spp;      // samples per pixel of the scheduler's cost probe; 0: chosen per frame (capi.hip)
 };
 // What the scheduler's probe pass leaves for the real pass (device pointers, all optional).
 struct SchedPlan {

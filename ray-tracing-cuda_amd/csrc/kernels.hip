@@ -471,7 +471,6 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.probe_marks = plan.probe_marks;
   lc.sparse_stride = tune.sparse_stride;
   lc.exclusive = tune.exclusive;
-  lc.priority = probe ? 0 : tune.priority;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),

@@ -20,7 +20,7 @@ struct LaunchCfg {
   int32_t list_off;    // byte offset of the per-wave regions of the shared candidate tests, -1: each lane tests its own
   int32_t paths_off;   // byte offset of the staged leaf-path words
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
-  int32_t priority;    // 1: the wave's issue priority follows the rank of the tiles it holds (needs tile_order)
+  int32_t pad2;
   int32_t nrm_off;     // byte offset of the staged TriNrm records (with pairs_off), -1: not staged
   int32_t pad3;
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
@@ -92,7 +92,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   const double inv_w = 1.0 / (double)fr.width, inv_h = 1.0 / (double)fr.height;
   const bool f32_jitter = w_pow2 && h_pow2 && fr.width <= (1 << 20) && fr.height <= (1 << 20);  // (wave-uniform)
   // per-lane pixel state
-  int64_t q = 0;
+  int32_t q32 = 0;  // the lane's work item (items < 2^31: make_frame); widened where it addresses memory
   int pi = 0, pj = 0, k = 0;
   bool has_px = false, done = false, active = false;
   bool heavy = false;  // a pixel of the queue's sparse head (see below)
@@ -129,15 +129,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   if (classes) end64 = lc.sparse_items[1], end32 = lc.sparse_items[2];
   int cls = 1;
   bool head_open = classes;  // (wave-uniform) the head queue may still hold items
-  // Issue priority (lc.priority, list variants): a pixel is a serial chain, so a frame ends when its longest chains
-  // do.  A lane remembers in which part of the longest-first order its pixel's tile sits (the first 1/16: 3, the
-  // first quarter: 2, the first half: 1, else 0) and the wave runs at the highest class among its live pixels:
-  // the SIMD's issue arbiter serves higher priorities first, so the longest chains advance at close to the speed
-  // of a wave that has the SIMD to itself while the bulk fills the remaining slots.
-  int prio_cls = 0;
-  const bool use_prio = !(F & F_BVH) && lc.priority != 0 && lc.tile_order != nullptr;
   auto take_item = [&](int64_t item) -> bool {  // false: ragged-tile padding (or nothing to sample), written as black
-    q = item;
+    q32 = (int32_t)item;
+    const int64_t q = item;
     int64_t idx = frame_pixel_of_rank(fr, fr.rank, q);
     if (idx < 0 || fr.spp <= 0) {
       out[q * 3 + 0] = 0.f, out[q * 3 + 1] = 0.f, out[q * 3 + 2] = 0.f;
@@ -165,6 +159,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
     // -------------------------------------------------------- sample / pixel bookkeeping
     if (!active && !done && has_px && k >= fr.spp) {
+      const int64_t q = (int64_t)q32;
       V3 c = color;
       if (fr.post) {  // ray_tracing.cu:78-83
         c = c / (float)fr.spp;
@@ -252,14 +247,6 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         if (lc.tile_order) item = (int64_t)lc.tile_order[nq >> 6] * 64 + (int64_t)(nq & 63);
         if (!take_item(item)) continue;
         heavy = nq < sparse_limit;
-        if (use_prio) prio_cls = (int64_t)nq * 16 < n_items ? 3 : (int64_t)nq * 4 < n_items ? 2 : (int64_t)nq * 2 < n_items ? 1 : 0;
-      }
-      if (use_prio) {  // (wave-uniform: some lane asked for a pixel this iteration)
-        const bool live_px = has_px && !done;
-        if (__builtin_amdgcn_ballot_w64(live_px && prio_cls == 3) != 0ull) __builtin_amdgcn_s_setprio(3);
-        else if (__builtin_amdgcn_ballot_w64(live_px && prio_cls == 2) != 0ull) __builtin_amdgcn_s_setprio(2);
-        else if (__builtin_amdgcn_ballot_w64(live_px && prio_cls == 1) != 0ull) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
       }
     }
     if (!active && !done) {

@@ -212,7 +212,7 @@ def test_render_opts_validation():
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(bad_size), dummy, dummy, None, None) == -1
     assert b"size" in L.rtmi_last_error()
     for kw in (dict(schedule=3), dict(threads_per_block=100), dict(threads_per_block=1024), dict(sparse_stride=12),
-               dict(exclusive=2), dict(blocks_per_cu=-1), dict(priority=2)):
+               dict(exclusive=2), dict(blocks_per_cu=-1), dict(probe_spp=65), dict(probe_spp=-1)):
         o = rtmi.render_opts(**kw)
         assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1, kw
         assert b"out of range" in L.rtmi_last_error()
@@ -221,7 +221,7 @@ def test_render_opts_validation():
         assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1 and b"head_pct" in L.rtmi_last_error()
     o = rtmi.render_opts(head_pct=(40, 50, 30))  # the classes' thresholds must not increase
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1 and b"must not increase" in L.rtmi_last_error()
-    ok = rtmi.render_opts(schedule=2, sparse_stride=8, exclusive=0, priority=1, head_pct=(90, 60, 20))
+    ok = rtmi.render_opts(schedule=2, sparse_stride=8, exclusive=0, probe_spp=8, head_pct=(90, 60, 20))
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(ok), dummy, dummy, None, None) == -1
     assert b"not committed" in L.rtmi_last_error()  # the options passed; the scene is what is missing
     # the call's counters + states copy + probe counts + tile costs and order + 32 words + the head list (16,384 entries)

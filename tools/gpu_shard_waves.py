@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box, stats build level 9: `RTMI_STATS_LEVEL=9 tools/mesh_stats.sh build` on the dev box first):
 where the time of ONE shard of a list-scene frame goes -- per-wave start / end / queries and per-pixel ray counts.
-usage: RTMI_LIB_PATH=.../librtmi_stats.so tools/gpu_shard_waves.py [workload c4] [r/G 0/8] [spp] [priority] [bpc]
+usage: RTMI_LIB_PATH=.../librtmi_stats.so tools/gpu_shard_waves.py [workload c4] [r/G 0/8] [spp] [probe_spp] [bpc]
 Writes gpurun_out/shard_waves_<tag>.npz and prints the digest."""
 import ctypes as C
 import json
@@ -21,13 +21,13 @@ r, G = (int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0/8").split("/")
 w = dict(bench.WORKLOADS[wl])
 if len(sys.argv) > 3 and int(sys.argv[3]) > 0:
     w["spp"] = int(sys.argv[3])
-prio = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+prio = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 bpc = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 from rtmi import scenes
 seed = scenes.SCENE_SEEDS[w["scene"]]
 scene = bench.build_scene(rtmi.SceneBuilder(seed), w["scene"], 1.0).commit()
 R = rtmi.Renderer(scene, w["size"], w["size"], w["spp"], w["depth"], True, rank=r, world_size=G).init_rng()
-opts = rtmi.render_opts(priority=prio, blocks_per_cu=bpc)
+opts = rtmi.render_opts(probe_spp=prio, blocks_per_cu=bpc)
 shape = R.launch_shape(opts)
 pristine = R.states.clone()
 R.render(opts=opts)
@@ -52,7 +52,7 @@ end = (t1 - start) / 100.0  # microseconds (100 MHz)
 beg = (t0 - start) / 100.0
 rays = float(counts.sum())
 tile = counts.reshape(-1, 64)
-d = {"workload": wl, "shard": [r, G], "spp": w["spp"], "priority": prio, "shape": shape, "kernel_ms_stats_build": ms,
+d = {"workload": wl, "shard": [r, G], "spp": w["spp"], "probe_spp": prio, "shape": shape, "kernel_ms_stats_build": ms,
      "rays": rays, "waves": int(n_waves), "wave_queries_sum": float(q.sum()),
      "lane_utilisation": rays / (q.sum() * 64.0),
      "wave_end_us_percentiles": {p: float(np.percentile(end, p)) for p in (1, 10, 25, 50, 75, 90, 99, 100)},
