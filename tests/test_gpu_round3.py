@@ -1,0 +1,256 @@
+"""Parity cases added in round 3 (all through the C ABI, against the oracle):
+  * the raw-frame Camera constructor (camera.cu:40-47) on the GPU path;
+  * world lists long enough to leave the first 32-pair chunk of the culled scan, to fill its LDS staging (128 pairs)
+    and to fall back to the plain scan beyond it -- with coincident entries for the tie rules (hitable_list.cu:18),
+    flat and through nested lists whose flattened length crosses those limits;
+  * the triangle-soup worlds of the round-2 fuzz campaign (tools/gpu_fuzz.py) that once overran the wave-wide
+    search stack (gpurun_out/r02b_fuzz.log: a GPU memory fault within the first 400 soups), as a regression;
+  * two renders of ONE scene in flight on two streams, each with its own rtmi_render_opts.d_scratch;
+  * rtmi_render_status / rtmi_gather (one rank).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oraclelib
+import rtmi
+from rtmi.scenes import v3, PI_D
+
+pytestmark = pytest.mark.gpu
+
+
+def render_pair(fill, h, w, spp, depth, post=True, seed=11, camera=None):
+    """Build the same world on the oracle and on the product, render both, return (gpu, oracle) tuples."""
+    import torch
+    res = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        b = make(seed)
+        if camera is None:
+            b.camera_pinhole(v3(0, 1.0, 3.0), v3(0, 0.6, -1), v3(0, 1, 0), PI_D / 3, w / h)
+        else:
+            camera(b)
+        fill(b)
+        res.append(b)
+    o, p = res
+    o_rgb, o_rays, o_states, o_total = o.render(h, w, spp, depth, post=post)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth, post).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    return (img.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32), R.total_rays()), (o_rgb, o_rays, o_total)
+
+
+def assert_same(g, o):
+    assert g[2] == o[2], "ray totals %d vs %d" % (g[2], o[2])
+    assert np.array_equal(g[1], o[1]), "%d pixels with different ray counts" % (g[1] != o[1]).sum()
+    assert np.array_equal(g[0], o[0], equal_nan=True), np.abs(g[0] - o[0]).max()
+
+
+# ------------------------------------------------------------------ camera.cu:40-47
+def test_raw_frame_camera_on_the_gpu_path():
+    """Camera(position, lower_left_corner, horizontal, vertical): the scene supplies the frame itself; u, v, w stay
+    unset and RayAt only reads the four vectors (camera.cu:40-47, 57-70).  An off-axis, sheared frame."""
+    def cam(b):
+        b.camera_raw(v3(0.3, 1.2, 3.0), v3(-2.1, -0.9, 0.4), v3(4.0, 0.3, -0.2), v3(0.25, 2.6, 0.1))
+
+    def fill(b):
+        b.sphere(v3(0, -100.5, -1), 100.0, b.lambertian(v3(0.5, 0.6, 0.4)))
+        b.sphere(v3(0, 0.5, -1), 0.5, b.metal(v3(0.8, 0.8, 0.9), 0.05))
+        b.parallelepiped([v3(-1.6, 0, -1.2), v3(-0.9, 0, -1.2), v3(-1.6, 0.8, -1.2), v3(-1.6, 0, -0.5)], b.lambertian(v3(0.7, 0.3, 0.3)))
+        b.parallelogram([v3(-1, 3, -2), v3(1, 3, -2), v3(-1, 3, 0)], b.diffuse_light(b.constant_texture(v3(4, 4, 4))))
+        b.sky()
+    g, o = render_pair(fill, 36, 52, 4, 10, camera=cam)
+    assert_same(g, o)
+    assert o[2] > 36 * 52 * 4 * 1.5  # the scene is in view
+
+
+# ------------------------------------------------------------------ long world lists
+def _quilt(b, n, rng, boxes_every=0, dup_every=7):
+    """n world-list entries (parallelograms; every `boxes_every`-th a box = six pairs) scattered in front of the
+    camera, every `dup_every`-th entry repeated verbatim a little later (equal t: the first must win)."""
+    mats = [b.lambertian(v3(*rng.uniform(0.2, 0.9, 3))) for _ in range(5)] + \
+           [b.metal(v3(0.8, 0.8, 0.7), 0.0), b.metal(v3(0.7, 0.8, 0.9), 0.3), b.dielectric(v3(1, 1, 1), 1.5)]
+    light = b.diffuse_light(b.constant_texture(v3(3, 3, 3)))
+    made = []
+    for i in range(n):
+        c = np.array([rng.uniform(-2.2, 2.2), rng.uniform(0.0, 2.0), rng.uniform(-3.5, -0.5)])
+        m = mats[int(rng.integers(0, len(mats)))]
+        if boxes_every and i % boxes_every == boxes_every - 1:
+            e = rng.uniform(0.15, 0.4, 3)
+            pts = [v3(*c), v3(c[0] + e[0], c[1], c[2]), v3(c[0], c[1] + e[1], c[2]), v3(c[0], c[1], c[2] + e[2])]
+            b.parallelepiped(pts, m)
+            made.append(("box", pts, m))
+        else:
+            e1, e2 = rng.uniform(-0.45, 0.45, 3), rng.uniform(-0.45, 0.45, 3)
+            pts = [v3(*c), v3(*(c + e1)), v3(*(c + e2))]
+            b.parallelogram(pts, m)
+            made.append(("pg", pts, m))
+        if dup_every and i % dup_every == dup_every - 1:
+            kind, pts, _ = made[int(rng.integers(0, len(made)))]
+            other = mats[int(rng.integers(0, len(mats)))]
+            (b.parallelepiped if kind == "box" else b.parallelogram)(pts, other)
+    b.parallelogram([v3(-3, -0.01, -5), v3(3, -0.01, -5), v3(-3, -0.01, 1)], mats[0])
+    b.parallelogram([v3(-1, 3.2, -3), v3(1, 3.2, -3), v3(-1, 3.2, -1)], light)
+    b.sky()
+
+
+@pytest.mark.parametrize("n,boxes_every", [(34, 0), (40, 0), (100, 0), (108, 0), (140, 0), (30, 3), (300, 5)])
+def test_long_world_lists_match_the_full_scan(n, boxes_every):
+    """34 / 40 entries (+ duplicates, floor, light): past the first 32-pair chunk of the culled scan; 100 / 108:
+    several chunks, up to its 128-pair LDS staging; 140 / 300 (with boxes: ~650 pairs): beyond it, the plain
+    wave-uniform walk.  Duplicated entries make equal-t ties within and across chunks."""
+    state = np.random.default_rng(4000 + n + boxes_every).bit_generator.state
+
+    def fill(b):
+        rng = np.random.default_rng(0)
+        rng.bit_generator.state = state
+        _quilt(b, n, rng, boxes_every)
+    g, o = render_pair(fill, 40, 56, 3, 12)
+    assert_same(g, o)
+
+
+@pytest.mark.parametrize("per_list", [30, 50])
+def test_nested_lists_whose_flattened_length_crosses_the_staging_limit(per_list):
+    """Three stretches of `per_list` parallelograms in HitableLists nested two deep, plus top-level entries: 95 pairs
+    (inside the culled scan's staging) and 155 (outside: plain walk); hitable_list.cuh:8."""
+    state = np.random.default_rng(77 + per_list).bit_generator.state
+
+    def fill(b):
+        rng = np.random.default_rng(0)
+        rng.bit_generator.state = state
+        mats = [b.lambertian(v3(*rng.uniform(0.2, 0.9, 3))) for _ in range(4)] + [b.metal(v3(0.9, 0.9, 0.9), 0.1)]
+
+        def pg():
+            c = np.array([rng.uniform(-2, 2), rng.uniform(0, 1.8), rng.uniform(-3.5, -0.5)])
+            b.parallelogram([v3(*c), v3(*(c + rng.uniform(-0.4, 0.4, 3))), v3(*(c + rng.uniform(-0.4, 0.4, 3)))],
+                            mats[int(rng.integers(0, len(mats)))])
+        b.sky()
+        b.list_begin()
+        for _ in range(per_list):
+            pg()
+        b.list_begin()
+        for _ in range(per_list):
+            pg()
+        b.list_end()
+        for _ in range(per_list):
+            pg()
+        b.list_end()
+        for _ in range(4):
+            pg()
+        b.parallelogram([v3(-1, 3.2, -3), v3(1, 3.2, -3), v3(-1, 3.2, -1)], b.diffuse_light(b.constant_texture(v3(3, 3, 3))))
+    g, o = render_pair(fill, 36, 48, 3, 10)
+    assert_same(g, o)
+
+
+# ------------------------------------------------------------------ triangle soups (round-2 fuzz campaign)
+def soup_world(seed):
+    """The soup generator of tools/gpu_fuzz.py (second campaign), seed for seed."""
+    rng = np.random.default_rng(50000 + seed)
+    h, w = int(rng.integers(16, 49)), int(rng.integers(16, 65))
+    spp, depth = int(rng.integers(1, 5)), int(rng.choice([2, 8, 20, 50]))
+    n_mesh = int(rng.integers(1, 4))
+    soups = []
+    for _ in range(n_mesh):
+        n = int(rng.choice([1, 5, 40, 300, 1500]))
+        c = rng.uniform(-1.2, 1.2, 3)
+        c[1] = abs(c[1]) * 0.5 + 0.2
+        c[2] -= 2.0
+        spread = float(rng.choice([0.05, 0.4, 1.0]))
+        base = rng.uniform(-spread, spread, (n, 1, 3)) + c
+        size = float(rng.choice([0.05, 0.3, 0.9]))
+        f = (base + rng.uniform(-size, size, (n, 3, 3))).astype(np.float32)
+        if rng.integers(0, 3) == 0:  # duplicated faces: equal t, ties by reference index
+            f = np.concatenate([f, f[: max(1, n // 3)]], 0)
+        soups.append((f, int(rng.choice([1, 2, 3, 8, 64, 2048])), int(rng.integers(0, 4))))
+    floor_sphere = bool(rng.integers(0, 2))
+
+    def fill(b):
+        ms = [b.lambertian(v3(0.8, 0.7, 0.6)), b.metal(v3(0.9, 0.9, 0.8), 0.1), b.dielectric(v3(1, 1, 1), 1.0),
+              b.dielectric(v3(0.9, 1, 0.9), 1.5)]
+        for f, kmin, mi in soups:
+            b.bvh(f, ms[mi], k_min=kmin)
+        if floor_sphere:
+            b.sphere(v3(0, -100.5, -1), 100.0, ms[0])
+        else:
+            b.parallelogram([v3(-30, -0.5, -30), v3(30, -0.5, -30), v3(-30, -0.5, 30)], ms[0])
+        b.sky()
+    return fill, h, w, spp, depth, [(s[0].shape[0], s[1], s[2]) for s in soups]
+
+
+def test_triangle_soups_of_the_round_2_campaign():
+    """Soup seeds 0..399 in one go (the campaign that produced the recorded fault ran `gpu_fuzz.py 0 300 400`): every
+    k_min class (1, 2, 3, 8, 64, 2048), duplicated faces, dielectrics of index 1 that pass straight through tens of
+    faces.  No abandoned search (rtmi_render_status inside Renderer.untile / total_rays) and no differing pixel."""
+    bad = []
+    classes = set()
+    for seed in range(400):
+        fill, h, w, spp, depth, what = soup_world(seed)
+        classes.update(k for _, k, _ in what)
+        g, o = render_pair(fill, h, w, spp, depth, post=False, seed=300 + seed,
+                           camera=lambda b, a=w / h: b.camera_pinhole(v3(0, 0.8, 1.8), v3(0, 0.4, -2), v3(0, 1, 0), PI_D / 3, a))
+        if not (g[2] == o[2] and np.array_equal(g[1], o[1]) and np.array_equal(g[0], o[0], equal_nan=True)):
+            bad.append((seed, what))
+    assert classes == {1, 2, 3, 8, 64, 2048}
+    assert not bad, bad[:5]
+
+
+# ------------------------------------------------------------------ two renders of one scene in flight
+def test_two_streams_render_one_scene_concurrently():
+    """rtmi_render_opts.d_scratch holds ALL per-call state (queue cursors, ray total, completion flag, scheduler
+    buffers): two shards of one committed scene rendered on two streams at once, longest-first scheduling forced,
+    equal what each gives alone -- image, ray counts, ray totals."""
+    import torch
+    import common
+    h = w = 96
+    spp, depth = 64, 12
+    b = common.build_scene(rtmi.SceneBuilder(1024), "cornell_box", 1.0).commit()
+    alone = []
+    for r in range(2):
+        R = rtmi.Renderer(b, h, w, spp, depth, True, rank=r, world_size=2).init_rng()
+        R.render(opts=rtmi.render_opts(schedule=2))
+        torch.cuda.synchronize()
+        alone.append((R.tiles.clone(), R.ray_counts.clone(), R.total_rays()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    Rs, scratch = [], []
+    for r in range(2):
+        R = rtmi.Renderer(b, h, w, spp, depth, True, rank=r, world_size=2).init_rng()
+        Rs.append(R)
+        scratch.append(R.new_scratch())
+    torch.cuda.synchronize()
+    for _ in range(3):  # several rounds: the two launches overlap in some of them at least
+        for r in range(2):
+            with torch.cuda.stream(streams[r]):
+                Rs[r].init_rng()
+                Rs[r].render(opts=rtmi.render_opts(schedule=2, scratch=scratch[r]))
+        torch.cuda.synchronize()
+        for r in range(2):
+            assert Rs[r].total_rays(scratch[r]) == alone[r][2]
+            assert torch.equal(Rs[r].ray_counts, alone[r][1])
+            assert torch.equal(Rs[r].tiles, alone[r][0])
+    # a scratch that is too small is refused before anything is launched
+    small = torch.zeros(64, dtype=torch.int64, device="cuda")
+    with pytest.raises(rtmi.RtmiError):
+        Rs[0].render(opts=rtmi.render_opts(scratch=small))
+
+
+def test_render_status_and_single_rank_gather():
+    import torch
+    import common
+    L = rtmi.lib()
+    b = common.build_scene(rtmi.SceneBuilder(1024), "cornell_box", 1.0).commit()
+    R = rtmi.Renderer(b, 24, 24, 2, 5).init_rng()
+    R.render()
+    rays = C.c_uint64(0)
+    assert L.rtmi_render_status(b.h, None, C.byref(rays), None) == 0 and rays.value == R.total_rays() > 0
+    assert L.rtmi_render_status(b.h, None, None, None) == 0  # the ray total is optional
+    # world_size 1: rtmi_gather is the device copy into the root's buffer, no communicator needed
+    allt = torch.full_like(R.tiles, -1.0)
+    assert L.rtmi_gather(None, C.byref(R.frame), C.c_void_p(R.tiles.data_ptr()), C.c_void_p(allt.data_ptr()), 0, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(allt, R.tiles)
+    two = rtmi.make_frame(24, 24, 2, 5, rank=0, world_size=2)
+    assert L.rtmi_gather(None, C.byref(two), C.c_void_p(R.tiles.data_ptr()), C.c_void_p(allt.data_ptr()), 0, None) == -1
+    assert b"communicator" in L.rtmi_last_error()
+    assert L.rtmi_reduce_sum(None, C.byref(R.frame), C.c_void_p(R.tiles.data_ptr()), 0, None) == 0

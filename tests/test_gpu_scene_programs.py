@@ -64,24 +64,131 @@ def test_spheres_program_matches_python_binding(tmp_path):
     assert (img == ref).all(axis=2).mean() > 0.98
 
 
+def write_ppm(path, rgb):
+    """Binary PPM (P6): the stb_image stand-in (api/compat/stb_image.h) decodes it losslessly, whatever the file is
+    called, so the texels the scene program samples are exactly the array the oracle is given."""
+    rgb = np.ascontiguousarray(rgb[..., :3], dtype=np.uint8)
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+        f.write(rgb.tobytes())
+
+
 def test_bunny_program_with_obj_stand_in(tmp_path):
+    """Model<false> (OBJ through api/model.h) -> BVH<Face<false>, AABB> -> DistributedMain, against the ORACLE's render
+    of the same 69,312 faces (reference leaf size 2048): the loader leg and the renderer in one comparison."""
     from rtmi import scenes
     assets(tmp_path)
     h, w, spp = 64, 64, 2
     img, log = run_scene("bunny", tmp_path, h, w, spp)
     assert "69312 faces in mesh 0" in log
-    ref, _, _, _, _ = common.gpu_render("bunny", h, w, spp, 10, faces=scenes.procedural_bunny_mesh())
+    mesh = scenes.procedural_bunny_mesh()
+    ref, _, _, _, _ = common.oracle_render("bunny", h, w, spp, 10, faces=mesh)
     assert common.rel_l2(img, ref) <= 1e-3
+    assert (img == ref).all(axis=2).mean() > 0.98  # (the device's tan() may move the camera frame by an ulp)
+    gpu, _, _, _, _ = common.gpu_render("bunny", h, w, spp, 10, faces=mesh)
+    assert np.array_equal(gpu, ref)  # the Python binding on the same mesh: bit for bit
+
+
+def test_birthday_program_against_the_oracle(tmp_path):
+    """scenes/birthday.cu through Main with a lossless stand-in for resources/earthmap.jpg, against the oracle's
+    render with the same texels, at the tolerance the image-textured sphere is held to everywhere (acosf / atan2f of
+    two libms pick the texel, sphere.cu:60-63): 1e-3 relative L2."""
+    from rtmi import scenes
+    (tmp_path / "resources").mkdir()
+    earth = scenes.procedural_earthmap(128, 256)
+    write_ppm(str(tmp_path / "resources" / "earthmap.jpg"), earth)
+    h, w, spp = 64, 64, 8
+    img, _ = run_scene("birthday", tmp_path, h, w, spp)
+    ref, _, _, _, _ = common.oracle_render("birthday", h, w, spp, 10, earthmap=earth)
+    rel = common.rel_l2(img, ref)
+    assert rel <= 1e-3, rel
+    centre = img[24:40, 24:40]  # the textured sphere: the map's colours, not a flat tone
+    assert centre.std(axis=(0, 1)).max() > 0.02
 
 
 def test_birthday_program_with_jpeg_stand_in(tmp_path):
+    """The same program on a real baseline JPEG (tools/make_assets.py), decoded by the stand-in's own decoder and,
+    for the oracle, by PIL: two IDCTs may differ by a level or two per texel, so this one is held to 5e-3."""
     assets(tmp_path)
-    h, w, spp = 64, 64, 4
+    from PIL import Image
+    h, w, spp = 64, 64, 8
     img, _ = run_scene("birthday", tmp_path, h, w, spp)
+    rgb = np.asarray(Image.open(str(tmp_path / "resources" / "earthmap.jpg")).convert("RGB"))
+    rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
+    ref, _, _, _, _ = common.oracle_render("birthday", h, w, spp, 10, earthmap=rgba)
     assert np.isfinite(img).all() and img.max() <= 1.0 and img.min() >= 0.0
-    # the textured sphere occupies the image centre: it must show the map's colours, not a flat tone
-    centre = img[24:40, 24:40]
-    assert centre.std(axis=(0, 1)).max() > 0.02
+    assert common.rel_l2(img, ref) <= 5e-3
+
+
+def quilt_model(tmp_path):
+    """A small OBJ with texture coordinates and two materials (the first with a map_Kd texture), its MTL and the
+    texture as resources/textures/quilt.ppm; returns (faces0, uvs0, faces1, uvs1, rgba)."""
+    res = tmp_path / "resources"
+    (res / "models").mkdir(parents=True)
+    (res / "textures").mkdir()
+    rng = np.random.default_rng(21)
+    n = 6
+    g = np.linspace(-1.0, 1.0, n + 1)
+    verts, uvs = [], []
+    for i in range(n + 1):
+        for j in range(n + 1):
+            y = 0.35 + 0.25 * np.sin(2.1 * g[i]) * np.cos(1.7 * g[j]) + rng.uniform(-0.03, 0.03)
+            verts.append(np.array([g[i], y, g[j] - 0.4], dtype=np.float32))
+            uvs.append(np.array([i / n, j / n], dtype=np.float32))
+    vid = lambda i, j: i * (n + 1) + j  # noqa: E731
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            tris.append((vid(i, j), vid(i + 1, j), vid(i + 1, j + 1)))
+            tris.append((vid(i, j), vid(i + 1, j + 1), vid(i, j + 1)))
+    half = len(tris) // 2
+    with open(str(res / "models" / "quilt.obj"), "w") as f:
+        f.write("mtllib quilt.mtl\n")
+        for p in verts:
+            f.write("v %.9g %.9g %.9g\n" % (p[0], p[1], p[2]))
+        for t in uvs:
+            f.write("vt %.9g %.9g\n" % (t[0], t[1]))
+        f.write("usemtl cloth\n")
+        for a, b, c in tris[:half]:
+            f.write("f %d/%d %d/%d %d/%d\n" % (a + 1, a + 1, b + 1, b + 1, c + 1, c + 1))
+        f.write("usemtl brass\n")
+        for a, b, c in tris[half:]:
+            # negative (relative) indices and a quad-free polygon syntax the loader must accept too
+            k = len(verts)
+            f.write("f %d/%d %d/%d %d/%d\n" % (a - k, a - k, b - k, b - k, c - k, c - k))
+    with open(str(res / "models" / "quilt.mtl"), "w") as f:
+        f.write("newmtl cloth\nKd 1 1 1\nmap_Kd some/dir/quilt.ppm\nnewmtl brass\nKd 0.8 0.7 0.5\n")
+    from rtmi import scenes
+    rgba = scenes.procedural_earthmap(32, 48)
+    write_ppm(str(res / "textures" / "quilt.ppm"), rgba)
+    V, T = np.asarray(verts), np.asarray(uvs)
+    out = []
+    for part in (tris[:half], tris[half:]):
+        idx = np.asarray(part)
+        out += [V[idx].astype(np.float32), T[idx].astype(np.float32)]
+    return out + [rgba]
+
+
+def test_textured_model_program_against_the_oracle(tmp_path):
+    """tests/scenes/textured_model.cu: Model<true> with `usemtl` / `mtllib` / `map_Kd` (model.h:76-91) feeding
+    BVH<Face<true>, AABB> under Lambertian(ImageTexture) and under Metal, through Main -- against the oracle's render
+    of the same faces, texture coordinates and texels.  No libm call decides a texel here (barycentric u, v:
+    bvh.cuh:41-45), so the frames agree except where the device's tan() moved the camera frame by an ulp."""
+    from rtmi.scenes import v3, PI_D
+    import oraclelib
+    f0, t0, f1, t1, rgba = quilt_model(tmp_path)
+    h, w, spp = 40, 56, 4
+    img, log = run_scene("textured_model", tmp_path, h, w, spp)
+    assert "loading texture" in log and "quilt.ppm" in log
+    o = oraclelib.OracleBuilder(1024)
+    o.camera_pinhole(v3(0.2, 1.1, 2.6), v3(0, 0.5, 0), v3(0, 1, 0), PI_D / 3, w / h)
+    o.parallelogram([v3(-4, 0, -4), v3(4, 0, -4), v3(-4, 0, 4)], o.lambertian(v3(0.55, 0.55, 0.5)))
+    o.sky()
+    o.bvh(f0, o.lambertian_tex(o.image_texture(rgba)), uvs=t0.reshape(-1, 6))
+    o.bvh(f1, o.metal(v3(0.8, 0.75, 0.6), 0.1), uvs=t1.reshape(-1, 6))
+    ref, _, _, _ = o.render(h, w, spp, 10)
+    assert common.rel_l2(img, ref) <= 1e-3
+    assert (img == ref).all(axis=2).mean() > 0.97
 
 
 def test_run_time_overrides_and_determinism(tmp_path):

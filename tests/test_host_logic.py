@@ -160,6 +160,47 @@ def test_error_behaviour():
     assert "(-4)" in str(e.value)
 
 
+def test_non_finite_geometry_is_refused():
+    """A NaN / infinite coordinate would poison the bounds of the search structures (the 4-wide tree's grid
+    quantisation never terminates on an infinite extent): every hitable refuses it with RTMI_ERR_INVALID.  The
+    reference would build such a mesh and never hit the face; a caller that wants that drops the face."""
+    L = rtmi.lib()
+    b = rtmi.SceneBuilder(1)
+    m = b.lambertian(v3(1, 1, 1))
+    inf, nan = float("inf"), float("nan")
+    with pytest.raises(rtmi.RtmiError):
+        b.sphere(v3(0, nan, 0), 1.0, m)
+    with pytest.raises(rtmi.RtmiError):
+        b.sphere(v3(0, 0, 0), inf, m)
+    with pytest.raises(rtmi.RtmiError):
+        b.triangle([v3(0, 0, 0), v3(1, inf, 0), v3(0, 1, 0)], m)
+    with pytest.raises(rtmi.RtmiError):
+        b.parallelogram([v3(0, 0, 0), v3(1, 0, 0), v3(0, nan, 0)], m)
+    with pytest.raises(rtmi.RtmiError):
+        b.parallelepiped([v3(0, 0, 0), v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, -inf)], m)
+    with pytest.raises(rtmi.RtmiError):
+        b.parallelepiped_lengths(v3(1, 1, 1), m, lambda p: p / 0.0 if p[0] else p * np.float32(inf))
+    faces = np.zeros((5, 3, 3), dtype=np.float32)
+    faces[3, 1, 2] = inf
+    with pytest.raises(rtmi.RtmiError) as e:
+        b.bvh(faces, m)
+    assert "non-finite" in str(e.value) and b"non-finite" in L.rtmi_last_error()
+    b.camera_pinhole(v3(0, 0, 1), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+    assert b.stats()["world"] == 0  # nothing was appended
+
+
+def test_exchange_argument_checks():
+    """rtmi_gather / rtmi_reduce_sum validate their arguments before they look for RCCL."""
+    L = rtmi.lib()
+    f = rtmi.make_frame(16, 16, 1, rank=1, world_size=2)
+    buf = (C.c_float * (2 * 64 * 3 * 2))()
+    assert L.rtmi_gather(None, C.byref(f), buf, buf, 5, None) == -1  # root outside the world
+    assert L.rtmi_gather(None, C.byref(f), None, buf, 0, None) == -1
+    root = rtmi.make_frame(16, 16, 1, rank=0, world_size=2)
+    assert L.rtmi_gather(None, C.byref(root), buf, None, 0, None) == -1 and b"d_all_tiles" in L.rtmi_last_error()
+    assert L.rtmi_reduce_sum(None, C.byref(f), None, 0, None) == -1
+
+
 def test_nested_list_bookkeeping():
     """A HitableList appended to a HitableList (hitable_list.cuh:8): one entry of its parent, up to
     kMaxHitables entries of its own, any nesting depth; brackets must balance."""
