@@ -11,7 +11,9 @@ import numpy as np
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _ORACLE_DIR = os.path.join(_ROOT, "oracle")
-_LIB_PATH = os.path.join(_ORACLE_DIR, "_build", "liboracle.so")
+# ORACLE_VARIANT=fma: the contraction-on build of oracle/Makefile, for tools/contraction_study.py ONLY (it checks nothing)
+_LIB_NAME = "liboracle_fma.so" if os.environ.get("ORACLE_VARIANT") == "fma" else "liboracle.so"
+_LIB_PATH = os.path.join(_ORACLE_DIR, "_build", _LIB_NAME)
 
 _TRANSFORM = C.CFUNCTYPE(None, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_void_p)
 
@@ -22,7 +24,7 @@ def build(force=False):
     stale = force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs if os.path.exists(s))
     if stale:
-        subprocess.run(["make", "-C", _ORACLE_DIR, "_build/liboracle.so"], check=True, capture_output=True)
+        subprocess.run(["make", "-C", _ORACLE_DIR, "_build/" + _LIB_NAME], check=True, capture_output=True)
     return _LIB_PATH
 
 
