@@ -438,7 +438,8 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t off = ((size_t)lc.lds_mats * sizeof(MatRec) + 15) & ~(size_t)15;
   lc.stack_off = (int32_t)off;
   const size_t levels = (size_t)(fr.max_depth > 0 ? fr.max_depth : 1);
-  size_t stack = (variant & F_TEX) ? 0 : (lc.wide_ids == 2 ? (levels + 1) / 2 : levels) * threads * (lc.wide_ids == 1 ? 2 : 1);
+  // image-textured variants: one 32-bit word per level (material id, or the sampled texel)
+  size_t stack = (variant & F_TEX) ? levels * threads * 4 : (lc.wide_ids == 2 ? (levels + 1) / 2 : levels) * threads * (lc.wide_ids == 1 ? 2 : 1);
   size_t noff = (off + stack + 15) & ~(size_t)15;
   lc.nodes_off = (int32_t)noff;
   lc.lds_nodes = (variant & F_BVH) ? (sc.n_nodes < kLdsNodes ? sc.n_nodes : kLdsNodes) : 0;

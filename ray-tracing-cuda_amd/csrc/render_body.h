@@ -108,8 +108,12 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // attenuation.  Without image textures the attenuation is the material's constant
   // colour and the layer is stored as a material id in LDS; with image textures the
   // sampled colour itself is kept (private memory).
-  constexpr int kAttFloats = (F & F_TEX) ? RTMI_KERNEL_MAX_DEPTH * 3 : 3;
-  float att[kAttFloats];
+  // (round 2 kept 64 x 3 floats of private memory per lane for this: 8.2 TB of scratch traffic per launch of a C5
+  // shard, 43 % of the waves' time spent waiting.)  Image-textured scenes: a layer is one 32-bit word in LDS,
+  // [level][thread] -- the material id, or bit 31 + the sampled texel's three bytes (trace_helpers.h: tex_fetch).
+  auto tex_layer_offset = [&](int level) -> uint32_t {
+    return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << 2);
+  };
 
   // Mesh variants, frames dominated by a few outlier tiles (their pixels bounce to the depth limit
   // inside the mesh, tens of times the median cost): the frame time is the serial chain of the
@@ -397,10 +401,13 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           V3 rgb = mk(m.r, m.g, m.b);
           RTMI_STAT2(if (!(F & F_BVH)) { const unsigned long long tsa = stat_now();  // (divergent code: first active lane reports)
             if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][9] += tsa - tq2; })
+          uint32_t layer = (uint32_t)mat;  // (F_TEX) what the fold will need of this bounce
           if (F & F_TEX) {
             if (m.tex >= 0 && (m.kind == MAT_LAMBERTIAN || m.kind == MAT_LIGHT)) {
               // image_texture.cu:11-13: v = 1.0 - v in double, then float coordinates
-              rgb = tex_sample(sc.texs[m.tex], tu, (float)(1.0 - (double)tv));
+              const uint32_t px = tex_fetch(sc.texs[m.tex], tu, (float)(1.0 - (double)tv));
+              layer = 0x80000000u | px;
+              if (m.kind == MAT_LIGHT) rgb = texel_rgb(px);
             }
           }
           if (m.kind == MAT_LIGHT) {
@@ -442,9 +449,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
             }
             if (scattered) {
               if (F & F_TEX) {
-                att[depth * 3 + 0] = rgb.x;
-                att[depth * 3 + 1] = rgb.y;
-                att[depth * 3 + 2] = rgb.z;
+                *reinterpret_cast<uint32_t *>(smem + tex_layer_offset(depth)) = layer;
               } else if (nibble_ids) {
                 const uint32_t at = ids_offset(depth >> 1);  // this lane's own byte: no other lane writes it
                 const uint32_t old = smem[at];
@@ -515,7 +520,14 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         for (; i >= 0; i--) {
           V3 a;
           if (F & F_TEX) {
-            a = mk(att[i * 3 + 0], att[i * 3 + 1], att[i * 3 + 2]);
+            const uint32_t lw = *reinterpret_cast<const uint32_t *>(smem + tex_layer_offset(i));
+            if (lw >> 31) {
+              a = texel_rgb(lw);  // the same byte / 255 the sample would have returned
+            } else if (mats_in_lds) {
+              a = lds_rgb((int)lw);
+            } else {
+              a = mk(sc.mats[lw].r, sc.mats[lw].g, sc.mats[lw].b);
+            }
           } else {
             const int mi = nibble_ids     ? (int)((smem[ids_offset(i >> 1)] >> ((i & 1) * 4)) & 15u)
                            : lc.wide_ids ? (int)*reinterpret_cast<const uint16_t *>(smem + ids_offset(i))

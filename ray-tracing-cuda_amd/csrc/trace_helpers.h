@@ -280,7 +280,11 @@ __device__ __forceinline__ float aabb_crossing_time(const BvhNode &nd, V3 o, V3 
   return m;
 }
 
-__device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) {
+// ImageTexture::Value (textures/image_texture.cu:9-15): tex2D<float4> of an RGBA8 image, point filter, wrap,
+// normalised coordinates.  The texel is fetched as its three colour bytes (r | g << 8 | b << 16) and turned into
+// the texture unit's floats -- byte / 255 -- by texel_rgb: a layer of the radiance fold can then be kept as ONE
+// word and its colour re-formed, by the same division, when the path is folded.
+__device__ __forceinline__ uint32_t tex_fetch(const TexRec &tx, float u, float v) {
   float fu = u - floorf(u), fv = v - floorf(v);
   int ix = (int)floorf(fu * (float)tx.width);
   int iy = (int)floorf(fv * (float)tx.height);
@@ -288,9 +292,13 @@ __device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) {
   iy = iy > tx.height - 1 ? tx.height - 1 : iy;
   ix = ix < 0 ? 0 : ix;
   iy = iy < 0 ? 0 : iy;
-  const uint8_t *px = tx.rgba + (size_t)iy * tx.pitch + (size_t)ix * 4;
-  return mk((float)px[0] / 255.0f, (float)px[1] / 255.0f, (float)px[2] / 255.0f);
+  const uint32_t px = *reinterpret_cast<const uint32_t *>(tx.rgba + (size_t)iy * tx.pitch + (size_t)ix * 4);
+  return px & 0xffffffu;
 }
+__device__ __forceinline__ V3 texel_rgb(uint32_t px) {
+  return mk((float)(px & 0xffu) / 255.0f, (float)((px >> 8) & 0xffu) / 255.0f, (float)((px >> 16) & 0xffu) / 255.0f);
+}
+__device__ __forceinline__ V3 tex_sample(const TexRec &tx, float u, float v) { return texel_rgb(tex_fetch(tx, u, v)); }
 
 // lambertian.cu:19-31 / metal.cu:27-36: rejection-sample the unit ball.
 // l = (float)pow((double)(x*x+y*y+z*z), 0.5) == sqrtf(sum) (double rounding of a square
