@@ -391,6 +391,10 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->pair_boxes, &d.pair_boxes))) return rc;
   if ((rc = upload(s, s->pair_pts, &d.pair_pts))) return rc;
   if ((rc = upload(s, s->tri_nrm, &d.tri_nrm))) return rc;
+  if ((rc = upload(s, s->sph_groups, &d.sph_groups))) return rc;
+  if ((rc = upload(s, s->sph_members, &d.sph_members))) return rc;
+  d.sph_mag = s->sph_mag;
+  d.n_sph_groups = (int)s->sph_groups.size();
   if ((rc = upload(s, s->bvh_recs, &d.bvhs))) return rc;
   if ((rc = upload(s, s->nodes, &d.nodes))) return rc;
   if ((rc = upload(s, s->qnodes, &d.qnodes))) return rc;

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void rng_init_kernel(uint64_t seed, FrameDev f
 #ifndef RTMI_TRIS_WAVES
 #define RTMI_TRIS_WAVES 6
 #endif
-#define RTMI_MIN_WAVES(F) (((F) & (F_BVH | F_TEX | F_SPHERE)) ? 1 : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
+#ifndef RTMI_BVH_WAVES
+#define RTMI_BVH_WAVES 1
+#endif
+#define RTMI_MIN_WAVES(F) (((F) & F_BVH) ? RTMI_BVH_WAVES : ((F) & (F_TEX | F_SPHERE | F_SGROUP)) ? 1 : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
 // Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
 // workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
 #define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)
@@ -454,9 +457,12 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t noff2 = (poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
   lc.nrm_off = cull ? (int32_t)noff2 : -1;
   size_t loff = (noff2 + (cull ? (size_t)sc.n_pairs * 2 * sizeof(TriNrm) : 0) + 15) & ~(size_t)15;
-  const bool share = cull;  // the culled scan always shares its candidate tests over the wave
+  const bool groups = (variant & F_SGROUP) && sc.n_sph_groups > 0;  // the grouped sphere scan shares its tests too
+  const bool share = cull || groups;
   lc.list_off = share ? (int32_t)loff : -1;
-  *lds_bytes = loff + (share ? (size_t)(threads / 64) * (64 * 8 + kListTasks * (1 + ((variant & F_TEX) ? 6 : 2))) * sizeof(int) : 0);
+  size_t coff = loff + (share ? (size_t)(threads / 64) * kListWaveWords(variant) * sizeof(int) : 0);
+  lc.cand_off = groups ? (int32_t)coff : -1;
+  *lds_bytes = coff + (groups ? (size_t)threads * kSphCand * sizeof(uint16_t) : 0);
   return lc;
 }
 
@@ -508,6 +514,8 @@ static int occupancy_t(const SceneDev &sc, const FrameDev &fr, int threads) {
   X(F_TRIS)                                          \
   X(F_SPHERE)                                        \
   X(F_TRIS | F_SPHERE)                               \
+  X(F_SPHERE | F_SGROUP)                             \
+  X(F_TRIS | F_SPHERE | F_SGROUP)                    \
   X(F_TRIS | F_BVH)                                  \
   X(F_TRIS | F_SPHERE | F_TEX)                       \
   X(F_ALL)

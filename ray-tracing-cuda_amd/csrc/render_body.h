@@ -22,7 +22,7 @@ struct LaunchCfg {
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
   int32_t pad2;
   int32_t nrm_off;     // byte offset of the staged TriNrm records (with pairs_off), -1: not staged
-  int32_t pad3;
+  int32_t cand_off;    // byte offset of the per-lane candidate slots of the grouped sphere scan, -1: none
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
   const uint32_t *head_list;     // optional (with sparse_items): the head's items by weight class (SchedPlan::head_list)
   const uint32_t *probe_marks;   // with head_list: bit 31 of an item's word = it is in the head
@@ -61,9 +61,13 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   }
   const float4 *s_nrm = reinterpret_cast<const float4 *>(smem + (lc.nrm_off >= 0 ? lc.nrm_off : 0));
   int *ll = nullptr;  // this wave's region for the shared candidate tests of the culled list scan
-  if ((F & F_TRIS) && lc.list_off >= 0)
+  if ((F & (F_TRIS | F_SGROUP)) && lc.list_off >= 0)
     ll = reinterpret_cast<int *>(smem + lc.list_off) +
-         __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * 8 + kListTasks * (1 + ((F & F_TEX) ? 6 : 2)));
+         __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * kListWaveWords(F);
+  uint16_t *cands = nullptr;  // this wave's candidate slots of the grouped sphere scan
+  if ((F & F_SGROUP) && lc.cand_off >= 0)
+    cands = reinterpret_cast<uint16_t *>(smem + lc.cand_off) +
+            __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * kSphCand);
   const bool mats_in_lds = lc.lds_mats > 0;
   auto lds_rgb = [&](int m) -> V3 {  // a staged material's colour: one 16-byte read (MatRec: r, g, b, kind)
     const float4 c = *reinterpret_cast<const float4 *>(s_mats + m);
@@ -310,9 +314,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
               const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
     Hit h = {};
-    const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && s_pairs != nullptr);  // wave-uniform
+    const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && s_pairs != nullptr) || ((F & F_SGROUP) && cands != nullptr);  // wave-uniform
     if (all_lanes_in)  // every lane goes in, with or without a ray of its own: see closest_hit
-      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, wl, counters + 2, o, d, active
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, cands, wl, counters + 2, o, d, active
 #ifdef RTMI_STATS
                          , st
 #endif
@@ -320,7 +324,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
     if (active) {
       if (!all_lanes_in)
-        h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, o, d, true
+        h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, nullptr, o, d, true
 #ifdef RTMI_STATS
                            , st
 #endif

@@ -64,6 +64,9 @@ struct Scene {
   std::vector<PairBox> pair_boxes;
   std::vector<PairPts> pair_pts;
   std::vector<TriNrm> tri_nrm;
+  std::vector<SphGroup> sph_groups;
+  std::vector<SphMember> sph_members;
+  float sph_mag = 0.f;
   float list_mag = 0.f;
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;

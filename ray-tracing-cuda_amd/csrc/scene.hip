@@ -467,6 +467,7 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
 
 std::string Scene::flatten() {
   pair_boxes.clear(), pair_pts.clear(), tri_nrm.clear(), list_mag = 0.f;
+  sph_groups.clear(), sph_members.clear(), sph_mag = 0.f;
   runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(), tops.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
@@ -506,7 +507,7 @@ std::string Scene::flatten() {
     if (!runs.empty() && runs.back().kind == kind && runs.back().first + stride * runs.back().count == first) {
       runs.back().count++;
     } else {
-      runs.push_back(Run{kind, first, 1, 0});
+      runs.push_back(Run{kind, first, 1, -1});  // pad: first SphGroup of a grouped sphere run, else -1
     }
   };
   auto check_mat = [&](int m) { return m >= 0 && m < (int)mats.size(); };
@@ -662,6 +663,58 @@ std::string Scene::flatten() {
   if (!face_uv.empty()) face_uv.resize(faces.size() * 6, 0.f);
   if (!faces.empty())  // the kernel fetches sub-leaf faces four at a time
     for (int i = 0; i < 4; i++) faces.push_back(FaceRec{});
+  // spatial groups for the long sphere runs (scene_dev.h: SphGroup)
+  for (Run &run : runs) {
+    if (run.kind != RUN_SPHERE || run.count < kSphGroupMin || run.count > 65535) continue;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < run.count; i++) {
+      const SphereRec &sp = spheres[run.first + i];
+      const double c[3] = {sp.cx, sp.cy, sp.cz};
+      for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], c[a]), hi[a] = std::max(hi[a], c[a]);
+    }
+    std::vector<std::pair<uint32_t, int>> order(run.count);
+    for (int i = 0; i < run.count; i++) {
+      const SphereRec &sp = spheres[run.first + i];
+      const double c[3] = {sp.cx, sp.cy, sp.cz};
+      uint32_t code = 0;
+      for (int a = 0; a < 3; a++) {
+        const double ext = hi[a] - lo[a];
+        uint32_t qv = ext > 0 ? (uint32_t)std::min(1023.0, std::floor((c[a] - lo[a]) / ext * 1024.0)) : 0u;
+        for (int bit = 0; bit < 10; bit++) code |= ((qv >> bit) & 1u) << (3 * bit + a);  // Morton interleave
+      }
+      order[i] = {code, i};
+    }
+    std::stable_sort(order.begin(), order.end());
+    run.pad = (int)sph_groups.size();
+    for (int g0 = 0; g0 < run.count; g0 += kSphGroupSize) {
+      SphGroup g{};
+      g.first = (int)sph_members.size();
+      g.count = std::min(kSphGroupSize, run.count - g0);
+      float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+      for (int k = 0; k < g.count; k++) {
+        const int idx = run.first + order[g0 + k].second;
+        const SphereRec &sp = spheres[idx];
+        SphMember m{};
+        m.cx = sp.cx, m.cy = sp.cy, m.cz = sp.cz, m.r2f = (float)sp.r2, m.orig = idx, m.r2 = sp.r2;
+        sph_members.push_back(m);
+        // the member's own box, generously: |radius| (1 + 2^-10) on every side
+        const float r = (float)(std::fabs(sp.radius) * (1.0 + 0x1p-10)) + 1e-30f;
+        const float c[3] = {sp.cx, sp.cy, sp.cz};
+        for (int a = 0; a < 3; a++) mn[a] = fminf(mn[a], c[a] - r), mx[a] = fmaxf(mx[a], c[a] + r);
+      }
+      float diag = 0.f, mag = 0.f;
+      for (int a = 0; a < 3; a++) diag = fmaxf(diag, mx[a] - mn[a]), mag = fmaxf(mag, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
+      const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
+      for (int a = 0; a < 3; a++) g.mn[a] = mn[a] - pad, g.mx[a] = mx[a] + pad;
+      sph_mag = fmaxf(sph_mag, mag);
+      sph_groups.push_back(g);
+    }
+  }
+  if (!sph_groups.empty()) features |= F_SGROUP;
+  if (!sph_groups.empty()) {  // look-ahead targets of the scalar ping-pong loads
+    sph_groups.push_back(SphGroup{});
+    sph_members.push_back(SphMember{});
+  }
   for (size_t t = 0; t < 2 * pair_pts.size() && t < tris.size(); t++) {
     TriNrm r{};
     for (int c = 0; c < 3; c++) r.n[c] = tris[t].n[c];

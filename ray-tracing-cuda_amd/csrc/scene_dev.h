@@ -33,6 +33,26 @@ struct SphereRec {  // 32 B
   double r2;  // radius * radius (pow(radius, 2), sphere.cu:16)
 };
 
+// Sphere runs of 32 or more spheres are searched through spatial GROUPS (closest_hit.h, RUN_SPHERE): the run's
+// spheres sorted along a Morton curve and cut into groups of up to 16.  Both records are read at a wave-uniform
+// index (one s_load_dwordx8 each).  What HitableList::Hit returns for a stretch of spheres is the smallest accepted
+// t, the first in list order among equal ones, so the order in which they are LOOKED AT is free (see the kernel);
+// `orig` keeps the list position for the tie rule.
+struct SphGroup {  // 32 B: bounds of the members' own boxes (centre -+ radius), padded; first member, count
+  float mn[3], mx[3];
+  int32_t first, count;
+};
+struct SphMember {  // 32 B: all the pre-test and the binary64 test need
+  float cx, cy, cz;
+  float r2f;       // (float)(radius * radius): operand of the binary32 pre-test
+  int32_t orig;    // index of the sphere in SceneDev::spheres (list order)
+  int32_t pad;
+  double r2;       // radius * radius (pow(radius, 2), sphere.cu:16)
+};
+constexpr int kSphGroupSize = 16;
+constexpr int kSphGroupMin = 32;   // shorter runs are scanned sphere by sphere
+constexpr int kSphCand = 32;       // candidate slots per lane in LDS (uint16 each); the scan flushes before a group could overflow them
+
 struct TriRec {  // 48 B: Moller-Trumbore operands that do not depend on the ray
   float p0[3];
   float e1[3];  // p1 - p0
@@ -79,6 +99,11 @@ struct alignas(16) TriNrm {
 };
 constexpr int kCullMinPairs = 4;  // shorter lists are scanned plainly: the cull and the hand-over through LDS cost more than they save
 constexpr int kListTasks = 192;  // (ray, pair) tasks of the culled list scan that one wave holds in LDS at a time
+// words of one wave's region for shared candidate tests: 64 ray records of 8 words, kListTasks tasks, and per task
+// the results -- t of a pair's two triangles (+ their u, v with image textures), or a sphere's v (binary64) and index
+constexpr int kListWaveWords(uint32_t features) {
+  return 64 * 8 + kListTasks * (1 + ((features & 16u) ? 6 : (features & 1u) ? 3 : 2));  // (16 = F_TEX, 1 = F_SPHERE)
+}
 constexpr int kLdsPairs = 128;  // at most this many PairPts records are staged in LDS (8 KiB); longer lists use the plain scan
 
 enum MatKind : int32_t { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_LIGHT = 3, MAT_SKY = 4 };
@@ -185,6 +210,10 @@ struct SceneDev {
   const SphereRec *spheres;
   const HotTri *tris;  // one inert record of padding follows the last (prefetch target)
   const PairBox *pair_boxes;  // per pair of `tris` records (index = tri index / 2), one inert record of padding
+  const SphGroup *sph_groups;  // per grouped sphere run: Run::pad = its first group, (count + 15) / 16 groups
+  const SphMember *sph_members;
+  float sph_mag;               // largest |coordinate| of the grouped spheres' bounds (scales the distance slack)
+  int32_t n_sph_groups;
   const PairPts *pair_pts;
   const TriNrm *tri_nrm;      // per `tris` record (2 * n_pairs), staged in LDS with pair_pts
   const BvhRec *bvhs;
@@ -215,10 +244,11 @@ struct SceneDev {
 enum : uint32_t {
   F_SPHERE = 1u,   // double-precision t
   F_TRIS = 2u,    // parallelograms / boxes / triangles in the world list
+  F_SGROUP = 4u,  // some sphere run is long enough for the grouped scan (with F_SPHERE)
   F_BVH = 8u,
   F_TEX = 16u,     // some material reads an image texture (u,v needed)
   F_DEFOCUS = 32u,
-  F_ALL = 59u
+  F_ALL = 63u
 };
 
 struct FrameDev {

@@ -202,6 +202,11 @@ __device__ __forceinline__ void cull_step(uint32_t &mask, float a, float b) {
   asm("v_cmp_le_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
 }
 
+// mask = 2 * mask + !(a < b)  (true for a NaN: what the pre-test cannot decide stays a candidate)
+__device__ __forceinline__ void cull_step_nlt(uint32_t &mask, float a, float b) {
+  asm("v_cmp_nlt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
+}
+
 // World-list triangle records are read through the constant address space: a
 // wave-uniform address there always selects scalar loads (one s_load_dwordx16 per
 // record into SGPRs) instead of per-lane vector loads.
@@ -216,6 +221,12 @@ __device__ __forceinline__ f32x8 load_pair_box(const PairBox *base, int idx) {
   return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
 }
 __device__ __forceinline__ f32x8 load_sphere(const SphereRec *base, int idx) {
+  return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
+}
+__device__ __forceinline__ f32x8 load_sph_group(const SphGroup *base, int idx) {
+  return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
+}
+__device__ __forceinline__ f32x8 load_sph_member(const SphMember *base, int idx) {
   return *(const RT_CONSTANT f32x8 *)(uintptr_t)(base + idx);
 }
 typedef int i32x16 __attribute__((ext_vector_type(16)));

@@ -254,3 +254,43 @@ def test_render_status_and_single_rank_gather():
     assert L.rtmi_gather(None, C.byref(two), C.c_void_p(R.tiles.data_ptr()), C.c_void_p(allt.data_ptr()), 0, None) == -1
     assert b"communicator" in L.rtmi_last_error()
     assert L.rtmi_reduce_sum(None, C.byref(R.frame), C.c_void_p(R.tiles.data_ptr()), 0, None) == 0
+
+
+# ------------------------------------------------------------------ long sphere runs (grouped scan)
+@pytest.mark.parametrize("n,seed", [(32, 0), (33, 1), (100, 2), (257, 3), (700, 4)])
+def test_long_sphere_runs_match_the_full_scan(n, seed):
+    """Stretches of 32 or more consecutive spheres go through the grouped scan (closest_hit.h): spatial groups of
+    16, per-lane pre-test, shared binary64 tests, an order-free fold -- smallest accepted t, FIRST in list order among
+    equal ones (hitable_list.cu:18).  Clouds with verbatim duplicates (equal t from different list positions),
+    concentric shells (far roots: rays that start inside a sphere, sphere.cu:32-38), glass and mirrors that send
+    rays back through the cloud from the far side, two runs separated by a parallelogram, and a camera INSIDE one of
+    the spheres."""
+    state = np.random.default_rng(9000 + seed).bit_generator.state
+
+    def fill(b):
+        rng = np.random.default_rng(0)
+        rng.bit_generator.state = state
+        mats = [b.lambertian(v3(*rng.uniform(0.2, 0.9, 3))) for _ in range(4)] + \
+               [b.metal(v3(0.85, 0.85, 0.8), 0.0), b.metal(v3(0.7, 0.8, 0.9), 0.4), b.dielectric(v3(1, 1, 1), 1.5),
+                b.dielectric(v3(0.95, 1, 0.95), 1.0), b.diffuse_light(b.constant_texture(v3(2.5, 2.5, 2.5)))]
+        b.sphere(v3(0, -1000.0, 0), 1000.0, mats[0])
+        made = []
+        half = n // 2
+        for i in range(n):
+            if i == half:
+                b.parallelogram([v3(-2, 0.0, -4.5), v3(2, 0.0, -4.5), v3(-2, 2.5, -4.5)], mats[4])  # splits the run
+            k = rng.integers(0, 10)
+            if k == 0 and made:  # verbatim duplicate with another material: equal roots, the first must win
+                c, r = made[int(rng.integers(0, len(made)))]
+            elif k == 1 and made:  # concentric shell around an earlier sphere
+                c, r0 = made[int(rng.integers(0, len(made)))]
+                r = r0 * float(rng.uniform(1.05, 1.6))
+            else:
+                c = np.array([rng.uniform(-2.5, 2.5), rng.uniform(0.1, 2.2), rng.uniform(-4.0, 1.0)])
+                r = float(rng.uniform(0.05, 0.35))
+            made.append((c, r))
+            b.sphere(v3(*c), r, mats[int(rng.integers(0, len(mats)))])
+        b.sphere(v3(0, 1.0, 3.0), 0.6, mats[7])  # the camera sits inside this one (index-1 glass)
+        b.sky()
+    g, o = render_pair(fill, 40, 56, 3, 12)
+    assert_same(g, o)
