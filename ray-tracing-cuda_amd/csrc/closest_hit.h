@@ -266,6 +266,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         }
       }
     }
+    bool grouped_done = false;  // (wave-uniform) the grouped scan has answered this sphere run
     if ((F & F_SGROUP) && run.kind == RUN_SPHERE && run.pad >= 0 && cands != nullptr) {
       // Long sphere runs (scenes/spheres.cu: 484 small spheres): the reference tests every sphere against every ray
       // (hitable_list.cu:11-22, sphere.cu:11-44).  What that RETURNS for a stretch of spheres is order-free: a
@@ -273,20 +274,21 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       // beyond the running t_to fails either way) -- does not depend on t_to, a sphere is accepted iff v <= t_to
       // (v < t_to once anything was hit), so the stretch yields its smallest v, the first in list order among equal
       // ones, accepted against the incoming t_to by that same rule.  Hence:
-      //  (1) the run's spheres sit in spatial groups of <= 16 (scene.hip); every lane slab-tests a group's padded
-      //      bounds, widened by 2^-9 of (|o| + the scene's size): the binary32 operands of the discriminant
+      //  (1) the run's spheres sit in spatial groups of <= 16 (scene.hip); every lane slab-tests every group's padded
+      //      bounds, widened by 2^-9 of (|o| + the group's own size): the binary32 operands of the discriminant
       //      (sphere.cu:13-17) let a ray that passes a sphere at distance m count as a hit up to
-      //      m^2 <= r^2 + 6e-7 |o - c|^2, i.e. within 8e-4 |o - c| of its surface; a group no lane touches is skipped;
-      //  (2) the members of a touched group go through the binary32 pre-test of the plain loop below (exact by its
-      //      margin), one bit per member and lane, no wave-wide decision per sphere;
-      //  (3) surviving (ray, sphere) pairs are kept per lane in LDS and, when a lane's slots could overflow or the
-      //      run ends, worked off by all 64 lanes like the candidate pairs of the triangle scan: lane l takes task l,
-      //      l + 64, ... and evaluates sphere.cu's binary64 arithmetic for that ray and that sphere;
+      //      m^2 <= r^2 + 6e-7 |o - c|^2, i.e. within 8e-4 |o - c| of its surface;
+      //  (2) the touched (ray, group) pairs are tasks for all 64 lanes -- lane l takes task l, l + 64, ... -- which
+      //      put the group's members through the binary32 pre-test of the plain loop below (exact by its margin) for
+      //      that ray; the survivors go to the ray owner's candidate slots in LDS;
+      //  (3) the (ray, sphere) candidates are tasks again: sphere.cu's binary64 arithmetic for that ray and sphere;
       //  (4) every lane folds its own results: smallest v, lowest list index among equal.
+      // A ray with more candidates than slots (kSphCand: it passes through that many spheres' neighbourhoods) sends
+      // its wave through the plain loop for this run instead.
       const int n_groups = (run.count + kSphGroupSize - 1) / kSphGroupSize;
       uint16_t *my_cands = cands + lane * kSphCand;
       int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks;
-      int ccnt = 0;
+      int ccnt = 0;  // candidates of this lane's ray
       bool have = false;
       double best_v = 0.0;
       int best_idx = 0;
@@ -295,14 +297,13 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         *reinterpret_cast<int4 *>(rr) = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), __float_as_int(saf));
         *reinterpret_cast<int4 *>(rr + 4) = make_int4(__float_as_int(d.x), __float_as_int(d.y), __float_as_int(d.z), 0);
       }
-      const float sdelta = 0x1p-9f * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + sc.sph_mag);
+      const float sdelta = 0x1p-9f * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));  // (the groups' bounds carry 2^-9 of their own size)
       const float six = __builtin_amdgcn_rcpf(d.x), siy = __builtin_amdgcn_rcpf(d.y), siz = __builtin_amdgcn_rcpf(d.z);
       const V3 s_inv = mk(fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : six, fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : siy,
                           fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : siz);
       const V3 s_klo = mk(-(o.x + sdelta) * s_inv.x, -(o.y + sdelta) * s_inv.y, -(o.z + sdelta) * s_inv.z);
       const V3 s_khi = mk(-(o.x - sdelta) * s_inv.x, -(o.y - sdelta) * s_inv.y, -(o.z - sdelta) * s_inv.z);
       const float s_lo0 = T_FROM_F * 0.999f, s_hi0 = (float)t_to * 1.0001f + 1e-6f;
-      const float a4 = 4.0f * saf;
       const int member0 = __float_as_int(load_sph_group(sc.sph_groups, run.pad)[6]);  // first member of the run
       // (3) + (4): all 64 lanes, whoever's the candidates are
       auto flush = [&]() {
@@ -363,53 +364,97 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         }
         ccnt = 0;
       };
-      f32x8 G = load_sph_group(sc.sph_groups, run.pad);
-      for (int g = 0; g < n_groups; g++) {
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): G has landed (see the triangle scan)
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x8 gb = G;
-        G = load_sph_group(sc.sph_groups, run.pad + g + 1);  // (one inert record follows the last group)
-        __builtin_amdgcn_sched_barrier(0);
-        const float t0x = __builtin_fmaf(gb[0], s_inv.x, s_klo.x), t1x = __builtin_fmaf(gb[3], s_inv.x, s_khi.x);
-        const float t0y = __builtin_fmaf(gb[1], s_inv.y, s_klo.y), t1y = __builtin_fmaf(gb[4], s_inv.y, s_khi.y);
-        const float t0z = __builtin_fmaf(gb[2], s_inv.z, s_klo.z), t1z = __builtin_fmaf(gb[5], s_inv.z, s_khi.z);
-        const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-        const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-        const bool touched = live && fmaxf(s_lo0, en) <= fminf(s_hi0, le);
-        if (!__any(touched)) continue;
-        const int gfirst = __float_as_int(gb[6]), gcount = __float_as_int(gb[7]);
-        if (__any(ccnt > kSphCand - kSphGroupSize)) flush();  // (wave-uniform) keep room for a whole group in every lane
-        uint32_t mask = 0u;
-        f32x8 M = load_sph_member(sc.sph_members, gfirst);
-        for (int i = 0; i < gcount; i++) {
-          __builtin_amdgcn_s_waitcnt(0xc07f);
+      // (1) + (2): group bounds per lane (one bit per group, 32 groups at a time), then the touched (ray, group) pairs
+      // as tasks for all 64 lanes: a task pre-tests the group's members against that ray and appends the survivors
+      // to the RAY OWNER's candidate slots (an LDS counter per lane).
+      int *counts = reinterpret_cast<int *>(cands + 64 * kSphCand);
+      counts[lane] = 0;
+      bool over = false;  // this lane found no room for a candidate of some ray: the wave falls back to the plain loop
+      for (int g0 = 0; g0 < n_groups; g0 += 32) {
+        const int ngc = n_groups - g0 < 32 ? n_groups - g0 : 32;
+        uint32_t gmask = 0u;
+        f32x8 G = load_sph_group(sc.sph_groups, run.pad + g0);
+        for (int g = 0; g < ngc; g++) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): G has landed (see the triangle scan)
           __builtin_amdgcn_sched_barrier(0);
-          const f32x8 mb = M;
-          M = load_sph_member(sc.sph_members, gfirst + i + 1);  // (one inert record follows the last member)
+          const f32x8 gb = G;
+          G = load_sph_group(sc.sph_groups, run.pad + g0 + g + 1);  // (one inert record follows the last group)
           __builtin_amdgcn_sched_barrier(0);
-          // the wave-level cull of the plain loop, per lane: when the binary32 discriminant is below -1e-5 of its
-          // terms' magnitude the exact one is negative; anything else (NaN included) stays a candidate
-          const V3 oc = o - mk(mb[0], mb[1], mb[2]);
-          const float bf = 2.0f * dot3(d, oc);
-          const float oc2 = dot3(oc, oc), r2f = mb[3];
-          const float bb = bf * bf;
-          const float disc_f = bb - a4 * (oc2 - r2f);
-          const float mag = bb + a4 * (oc2 + r2f);
-          cull_step_nlt(mask, disc_f, -1e-5f * mag);
+          const float t0x = __builtin_fmaf(gb[0], s_inv.x, s_klo.x), t1x = __builtin_fmaf(gb[3], s_inv.x, s_khi.x);
+          const float t0y = __builtin_fmaf(gb[1], s_inv.y, s_klo.y), t1y = __builtin_fmaf(gb[4], s_inv.y, s_khi.y);
+          const float t0z = __builtin_fmaf(gb[2], s_inv.z, s_klo.z), t1z = __builtin_fmaf(gb[5], s_inv.z, s_khi.z);
+          const float en = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+          const float le = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+          cull_step(gmask, fmaxf(s_lo0, en), fminf(s_hi0, le));
         }
-        mask = touched ? __brev(mask) >> (32 - gcount) : 0u;  // bit i = member i of the group
-        const int rel = gfirst - member0;
-        for (uint32_t m = mask; m != 0u; m &= m - 1u) my_cands[ccnt++] = (uint16_t)(rel + __builtin_ctz(m));
+        gmask = live ? __brev(gmask) >> (32 - ngc) : 0u;  // bit g = group g0 + g
+        const int cnt = __builtin_popcount(gmask);
+        const int base = wave_prefix_excl(cnt);
+        bool todo = cnt != 0;
+        while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
+          const int lo_t = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
+          const bool now = todo && base + cnt - lo_t <= kListTasks;
+          const int n_now = __builtin_amdgcn_readlane(base + cnt, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo_t;
+          if (now) {
+            int k = base - lo_t;
+            for (uint32_t m = gmask; m != 0u; m &= m - 1u) tasks[k++] = (lane << 16) | (g0 + __builtin_ctz(m));
+          }
+          wave_lds_fence();
+          for (int t0 = 0; t0 < n_now; t0 += 64) {
+            const int ti = t0 + lane;
+            if (ti < n_now) {
+              const int w = tasks[ti];
+              const int owner = w >> 16;
+              const int *orr = ll + owner * 8;
+              const float4 r0 = *reinterpret_cast<const float4 *>(orr), r1 = *reinterpret_cast<const float4 *>(orr + 4);
+              const V3 ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
+              const float ta4 = 4.0f * r0.w;
+              const int2 gr = *reinterpret_cast<const int2 *>(reinterpret_cast<const char *>(sc.sph_groups + run.pad + (w & 0xffff)) + 24);
+              const int rel = gr.x - member0;
+              const float4 *mp = reinterpret_cast<const float4 *>(sc.sph_members + gr.x);  // per-lane gathers (L1 / L2 resident)
+#pragma unroll 4
+              for (int i = 0; i < kSphGroupSize; i++) {
+                if (i < gr.y) {
+                  // the wave-level cull of the plain loop, per ray: when the binary32 discriminant is below -1e-5 of
+                  // its terms' magnitude the exact one is negative; anything else (NaN included) stays a candidate
+                  const float4 mb = mp[2 * i];
+                  const V3 oc = ro - mk(mb.x, mb.y, mb.z);
+                  const float bf = 2.0f * dot3(rd, oc);
+                  const float oc2 = dot3(oc, oc);
+                  const float bb = bf * bf;
+                  const float disc_f = bb - ta4 * (oc2 - mb.w);
+                  const float mag = bb + ta4 * (oc2 + mb.w);
+                  if (!(disc_f < -1e-5f * mag)) {
+                    const int slot = atomicAdd(&counts[owner], 1);
+                    if (slot < kSphCand) {
+                      cands[owner * kSphCand + slot] = (uint16_t)(rel + i);
+                    } else {
+                      over = true;
+                    }
+                  }
+                }
+              }
+            }
+          }
+          wave_lds_fence();
+          if (now) todo = false;
+        }
       }
-      flush();
-      if (have) {  // hitable_list.cu:13-19 against the state the run was entered with
-        const bool hit = best_v <= (double)t_to;
-        const bool acc = hit && (!ok || best_v < (double)t_to);
-        ok = ok || acc;
-        t_to = acc ? (T)best_v : t_to;
-        win = acc ? make_id(RUN_SPHERE, best_idx) : win;
+      const bool overflowed = __any(over);  // (wave-uniform)
+      if (!overflowed) {
+        ccnt = counts[lane];
+        flush();
+        if (have) {  // hitable_list.cu:13-19 against the state the run was entered with
+          const bool hit = best_v <= (double)t_to;
+          const bool acc = hit && (!ok || best_v < (double)t_to);
+          ok = ok || acc;
+          t_to = acc ? (T)best_v : t_to;
+          win = acc ? make_id(RUN_SPHERE, best_idx) : win;
+        }
+        grouped_done = true;
       }
-    } else if ((F & F_SPHERE) && live && run.kind == RUN_SPHERE) {
+    }
+    if ((F & F_SPHERE) && live && run.kind == RUN_SPHERE && !grouped_done) {
       f32x8 nxt = load_sphere(sc.spheres, run.first);
       for (int i = 0; i < run.count; i++) {
         __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): see the triangle loop

@@ -67,7 +67,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   uint16_t *cands = nullptr;  // this wave's candidate slots of the grouped sphere scan
   if ((F & F_SGROUP) && lc.cand_off >= 0)
     cands = reinterpret_cast<uint16_t *>(smem + lc.cand_off) +
-            __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * kSphCand);
+            __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * kSphCand + 128);  // slots + 64 counters
   const bool mats_in_lds = lc.lds_mats > 0;
   auto lds_rgb = [&](int m) -> V3 {  // a staged material's colour: one 16-byte read (MatRec: r, g, b, kind)
     const float4 c = *reinterpret_cast<const float4 *>(s_mats + m);

@@ -672,6 +672,12 @@ std::string Scene::flatten() {
       const double c[3] = {sp.cx, sp.cy, sp.cz};
       for (int a = 0; a < 3; a++) lo[a] = std::min(lo[a], c[a]), hi[a] = std::max(hi[a], c[a]);
     }
+    // spheres much larger than the typical one (a ground sphere among marbles) are kept together, behind the rest:
+    // in a group of small ones they would blow its bounds up to their own
+    std::vector<double> radii(run.count);
+    for (int i = 0; i < run.count; i++) radii[i] = std::fabs(spheres[run.first + i].radius);
+    std::nth_element(radii.begin(), radii.begin() + run.count / 2, radii.end());
+    const double big = 8.0 * radii[run.count / 2];
     std::vector<std::pair<uint32_t, int>> order(run.count);
     for (int i = 0; i < run.count; i++) {
       const SphereRec &sp = spheres[run.first + i];
@@ -682,6 +688,7 @@ std::string Scene::flatten() {
         uint32_t qv = ext > 0 ? (uint32_t)std::min(1023.0, std::floor((c[a] - lo[a]) / ext * 1024.0)) : 0u;
         for (int bit = 0; bit < 10; bit++) code |= ((qv >> bit) & 1u) << (3 * bit + a);  // Morton interleave
       }
+      if (std::fabs(sp.radius) > big) code |= 0x80000000u;
       order[i] = {code, i};
     }
     std::stable_sort(order.begin(), order.end());
@@ -704,7 +711,9 @@ std::string Scene::flatten() {
       }
       float diag = 0.f, mag = 0.f;
       for (int a = 0; a < 3; a++) diag = fmaxf(diag, mx[a] - mn[a]), mag = fmaxf(mag, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
-      const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
+      // + the scene-dependent part of the distance slack, 2^-9 of the group's own largest coordinate (the kernel adds
+      // the ray's: 2^-9 |o|): together at least 8e-4 |o - c| for every member, see closest_hit.h
+      const float pad = 1e-4f * diag + 1e-5f * mag + 0x1p-9f * mag + 1e-30f;
       for (int a = 0; a < 3; a++) g.mn[a] = mn[a] - pad, g.mx[a] = mx[a] + pad;
       sph_mag = fmaxf(sph_mag, mag);
       sph_groups.push_back(g);

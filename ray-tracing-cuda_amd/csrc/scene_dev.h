@@ -51,7 +51,7 @@ struct SphMember {  // 32 B: all the pre-test and the binary64 test need
 };
 constexpr int kSphGroupSize = 16;
 constexpr int kSphGroupMin = 32;   // shorter runs are scanned sphere by sphere
-constexpr int kSphCand = 32;       // candidate slots per lane in LDS (uint16 each); the scan flushes before a group could overflow them
+constexpr int kSphCand = 16;       // candidate slots per lane in LDS (uint16 each); the scan flushes before a group could overflow them
 
 struct TriRec {  // 48 B: Moller-Trumbore operands that do not depend on the ray
   float p0[3];

@@ -294,3 +294,24 @@ def test_long_sphere_runs_match_the_full_scan(n, seed):
         b.sky()
     g, o = render_pair(fill, 40, 56, 3, 12)
     assert_same(g, o)
+
+
+def test_a_ray_through_more_spheres_than_candidate_slots():
+    """48 concentric shells (and 40 more spheres elsewhere, so that the run is grouped): every ray towards the centre
+    passes through all of them -- more candidates than a lane's 16 slots -- and its wave answers the run with the
+    plain loop instead (closest_hit.h: `overflowed`)."""
+    def fill(b):
+        rng = np.random.default_rng(5)
+        glass = b.dielectric(v3(1, 1, 1), 1.0)   # index 1: rays go straight through every shell
+        tint = b.dielectric(v3(0.97, 0.99, 0.97), 1.0)
+        core = b.lambertian(v3(0.8, 0.3, 0.2))
+        for k in range(48):
+            b.sphere(v3(0, 1.0, -1.5), 0.25 + 0.02 * k, tint if k % 3 else glass)
+        b.sphere(v3(0, 1.0, -1.5), 0.2, core)
+        for _ in range(40):
+            b.sphere(v3(rng.uniform(-2.5, 2.5), rng.uniform(0.1, 2.0), rng.uniform(-4, 0)), float(rng.uniform(0.05, 0.2)),
+                     b.lambertian(v3(*rng.uniform(0.2, 0.9, 3))))
+        b.sphere(v3(0, -1000.0, 0), 1000.0, b.lambertian(v3(0.5, 0.5, 0.5)))
+        b.sky()
+    g, o = render_pair(fill, 32, 40, 2, 60)
+    assert_same(g, o)
