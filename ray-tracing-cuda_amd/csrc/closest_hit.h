@@ -39,7 +39,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   // the ray as the culled list scan wants it: 1/d (the hardware reciprocal will do: the test is conservative by
   // a margin of 1e-5, not 1e-7), and -(o +- delta)/d per axis, delta = the distance slack of the mesh search
   V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
-  if ((F & F_TRIS) && s_pairs != nullptr) {
+  // the culled list scan is on when the wave has its task region (ll) and the scene has pair records; the pairs'
+  // corners come from LDS when the list was short enough to be staged (s_pairs), else from global memory
+  const bool cull_list = (F & F_TRIS) && ll != nullptr && sc.n_pairs >= kCullMinPairs;  // (wave-uniform)
+  if ((F & F_TRIS) && cull_list) {
     const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
     cull_inv = mk(fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : ix, fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : iy,
                   fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : iz);
@@ -61,7 +64,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       t_to = acc ? ts : t_to;
       win = acc ? make_id(RUN_SKY, 0) : win;
     }
-    if ((F & F_TRIS) && run.kind == RUN_TRIS && s_pairs != nullptr) {
+    if ((F & F_TRIS) && run.kind == RUN_TRIS && cull_list) {
       // Culled scan (DESIGN.md "World-list scan").  The reference tests every entry of the list against
       // every ray (hitable_list.cu:11-22); what it RETURNS only depends on the entries whose test can
       // succeed, visited in list order.  Lanes of a wave carry unrelated rays, so no entry can be
@@ -167,8 +170,15 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                   t0_to = (T)r0.w;
                 }
                 const V3 ro = mk(r0.x, r0.y, r0.z), rd = mk(r1.x, r1.y, r1.z);
-                const float4 *pp = s_pairs + (size_t)(pair0 + c0 + (w & 31)) * 4;
-                const float4 qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                const size_t pidx = (size_t)(pair0 + c0 + (w & 31)) * 4;
+                float4 qa, qb, qc, qd;
+                if (s_pairs != nullptr) {  // (wave-uniform) staged in LDS
+                  const float4 *pp = s_pairs + pidx;
+                  qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                } else {  // a list too long for the staging: per-lane gather of 64 bytes (L1 / L2 resident)
+                  const float4 *pp = reinterpret_cast<const float4 *>(sc.pair_pts) + pidx;
+                  qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                }
                 const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
                 float ta = 0.f, ua = 0.f, va = 0.f, tb = 0.f, ub = 0.f, vb = 0.f;
                 const V3 e1 = p1 - p0, e2 = p2 - p0;  // utils.cu:54-55, the subtractions scene.hip: make_tri does

@@ -453,11 +453,13 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
   size_t soff = (paoff + (size_t)lc.lds_paths * sizeof(int32_t) + 15) & ~(size_t)15;
   lc.mesh_off = (int32_t)soff;
   size_t poff = soff + ((variant & F_BVH) ? (size_t)(threads / 64) * kMeshWaveWords * sizeof(int) : 0);
-  const bool cull = (variant & F_TRIS) && sc.n_pairs >= kCullMinPairs && sc.n_pairs <= kLdsPairs && !plain_list_scan();
-  lc.pairs_off = cull ? (int32_t)poff : -1;
-  size_t noff2 = (poff + (cull ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
-  lc.nrm_off = cull ? (int32_t)noff2 : -1;
-  size_t loff = (noff2 + (cull ? (size_t)sc.n_pairs * 2 * sizeof(TriNrm) : 0) + 15) & ~(size_t)15;
+  // the culled list scan: any list of four or more pairs; its records are staged in LDS up to kLdsPairs pairs
+  const bool cull = (variant & F_TRIS) && sc.n_pairs >= kCullMinPairs && !plain_list_scan();
+  const bool staged = cull && sc.n_pairs <= kLdsPairs;
+  lc.pairs_off = staged ? (int32_t)poff : -1;
+  size_t noff2 = (poff + (staged ? (size_t)sc.n_pairs * sizeof(PairPts) : 0) + 15) & ~(size_t)15;
+  lc.nrm_off = staged ? (int32_t)noff2 : -1;
+  size_t loff = (noff2 + (staged ? (size_t)sc.n_pairs * 2 * sizeof(TriNrm) : 0) + 15) & ~(size_t)15;
   const bool groups = (variant & F_SGROUP) && sc.n_sph_groups > 0;  // the grouped sphere scan shares its tests too
   const bool share = cull || groups;
   lc.list_off = share ? (int32_t)loff : -1;

@@ -16,7 +16,8 @@ struct LaunchCfg {
   int32_t lds_nodes;   // reference-tree nodes staged in LDS (the first lds_nodes of SceneDev::nodes)
   int32_t mesh_off;    // byte offset of the per-wave mesh-search regions (kMeshWaveWords words each; BVH variants)
   int32_t exclusive;   // 1: while a wave holds an outlier pixel, its other lanes take no new pixels (they work for it)
-  int32_t pairs_off;   // byte offset of the staged PairPts records, -1: not staged (plain list scan)
+  int32_t pairs_off;   // byte offset of the staged PairPts records, -1: not staged (the culled scan, if on, gathers them
+                       // from global memory)
   int32_t list_off;    // byte offset of the per-wave regions of the shared candidate tests, -1: each lane tests its own
   int32_t paths_off;   // byte offset of the staged leaf-path words
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
@@ -314,7 +315,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(wave_queries++; const unsigned long long tq1 = stat_now(); st.cyc[0] += tq1 - tq0;
               const unsigned long long in0 = st.cyc[2] + st.cyc[3];)
     Hit h = {};
-    const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && s_pairs != nullptr) || ((F & F_SGROUP) && cands != nullptr);  // wave-uniform
+    const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && ll != nullptr && sc.n_pairs >= kCullMinPairs) ||
+                              ((F & F_SGROUP) && cands != nullptr);  // wave-uniform
     if (all_lanes_in)  // every lane goes in, with or without a ray of its own: see closest_hit
       h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, cands, wl, counters + 2, o, d, active
 #ifdef RTMI_STATS
