@@ -162,6 +162,9 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     return true;
   };
 
+#ifdef RTMI_CHECK_MARGINS
+  unsigned check_tick = (blockIdx.x * 7u + (threadIdx.x >> 6)) & 255u;  // (wave-uniform) stagger the waves' samples
+#endif
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
             const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
   for (;;) {
@@ -324,6 +327,21 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 #endif
       );
     RTMI_STAT(const unsigned long long tq2 = stat_now(); st.cyc[1] += (tq2 - tq1) - (st.cyc[2] + st.cyc[3] - in0);)
+#ifdef RTMI_CHECK_MARGINS
+    // Diagnostic build (tools/check_margins.sh): every 256th query of a wave is answered a second time WITHOUT the
+    // per-lane culls -- the plain wave-uniform walk of the world list, the plain sphere loop -- and compared: a
+    // padded bound or distance slack that let an acceptable primitive slip (closest_hit.h, scene.hip) shows as a
+    // disagreement.  counters[33] += rays re-done, counters[34] += disagreements (rtmi_debug_counters).
+    if (all_lanes_in && !(F & F_BVH) && (check_tick++ & 255u) == 0u) {
+      const Hit h2 = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, nullptr, nullptr, nullptr, nullptr, nullptr, o, d, active);
+      const bool differs = active && (h2.ok != h.ok || (h.ok && (__float_as_uint(h2.t) != __float_as_uint(h.t) || h2.win != h.win)));
+      const unsigned long long na = __builtin_amdgcn_ballot_w64(active), nd = __builtin_amdgcn_ballot_w64(differs);
+      if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(&counters[33], (unsigned long long)__popcll(na));
+        if (nd) atomicAdd(&counters[34], (unsigned long long)__popcll(nd));
+      }
+    }
+#endif
     if (active) {
       if (!all_lanes_in)
         h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, nullptr, o, d, true

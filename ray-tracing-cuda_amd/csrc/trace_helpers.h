@@ -266,9 +266,13 @@ __device__ __forceinline__ bool aabb_test(const BvhNode &nd, V3 o, V3 d, T t_to)
 }
 
 // The T-independent part of AABB::Hit (bvh.cu:6-30): the smallest plane-crossing time tf that is
-// finite, >= t_from and whose crossing point lies inside the box on the other two axes (+inf if no
-// plane qualifies).  AABB::Hit(box, [t_from, T]) is then exactly `crossing_time <= T`: each plane's
-// own test is `tf <= T` AND these T-independent conditions, and the box test is their OR.
+// finite, >= t_from and whose crossing point lies inside the box on the other two axes -- a NaN if no
+// plane qualifies.  AABB::Hit(box, [t_from, T]) is then exactly `crossing_time <= T`: each plane's
+// own test is `tf <= T` AND these T-independent conditions, and the box test is their OR.  (The "none"
+// marker must compare false against EVERY T: +infinity would not -- T is +infinity for a mesh that comes first in
+// the world list -- and did not until round 3: a face accepted by the binary32 triangle test from far outside
+// its leaf's box, rays 1e3 away from millimetre faces, was then reported although the reference never enters
+// that leaf.  tests/test_gpu_round3.py::test_far_false_accepts_outside_their_leaf_box.)
 __device__ __forceinline__ float aabb_crossing_time(const BvhNode &nd, V3 o, V3 d) {
   const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
   float m = INFINITY;
@@ -288,7 +292,7 @@ __device__ __forceinline__ float aabb_crossing_time(const BvhNode &nd, V3 o, V3 
       m = okp ? fminf(m, tf) : m;
     }
   }
-  return m;
+  return m < INFINITY ? m : __int_as_float(0x7fc00000);  // (every qualifying tf is finite)
 }
 
 // ImageTexture::Value (textures/image_texture.cu:9-15): tex2D<float4> of an RGBA8 image, point filter, wrap,

@@ -315,3 +315,50 @@ def test_a_ray_through_more_spheres_than_candidate_slots():
         b.sky()
     g, o = render_pair(fill, 32, 40, 2, 60)
     assert_same(g, o)
+
+
+# ------------------------------------------------------------------ far views of thin faces
+def sliver_fan(angle_deg, n=64, size=2e-3, seed=3):
+    """n thin triangles (apex angle `angle_deg`, legs of `size`) scattered over a 4 cm patch around the origin."""
+    rng = np.random.default_rng(seed)
+    faces = []
+    a = np.deg2rad(angle_deg)
+    for _ in range(n):
+        c = np.array([rng.uniform(-0.02, 0.02), rng.uniform(-1e-3, 1e-3), rng.uniform(-0.02, 0.02)])
+        th = rng.uniform(0, 2 * np.pi)
+        u = np.array([np.cos(th), 0.05 * rng.uniform(-1, 1), np.sin(th)])
+        v = np.array([np.cos(th + a), 0.05 * rng.uniform(-1, 1), np.sin(th + a)])
+        faces.append([c, c + size * u, c + size * v])
+    return np.asarray(faces, dtype=np.float32)
+
+
+@pytest.mark.parametrize("angle", [5.0, 1.4, 0.5, 0.1])
+@pytest.mark.parametrize("dist", [1e2, 1e3, 4e3, 2e4])
+def test_far_false_accepts_outside_their_leaf_box(angle, dist):
+    """Millimetre slivers (apex angles from 5 degrees down to 0.1) seen from 1e2 .. 2e4 away, the mesh FIRST in the
+    world list (t_to is still +infinity when BVH::Hit is entered) and reference leaves of 8 faces.  From that far the
+    binary32 triangle test (utils.cu:49-85) accepts rays that pass a sliver at many times its width -- streaks tens of
+    pixels long -- but the reference only reports such a face if the ray also crosses the exact, unpadded boxes on the
+    way to its leaf (bvh.cu:6-30), which such a ray usually does not.  The search must find the face (distance
+    slack of the search boxes), and the replay of the reference's box tests must then drop it: a box none of whose
+    planes qualifies has no crossing time, whatever t_to is (the round-3 fix in aabb_crossing_time).
+    Documents the sliver regime as well: at these angles and distances the frames still agree bit for bit."""
+    import torch
+    faces = sliver_fan(angle)
+    h, w, spp, depth = 48, 64, 2, 3
+    res = []
+    for make in (oraclelib.OracleBuilder, rtmi.SceneBuilder):
+        b = make(9)
+        pos = v3(0.3 * dist * 0.01, dist * np.sin(0.6), dist * np.cos(0.6))
+        b.camera_pinhole(pos, v3(0.0, 0, 0.0), v3(0, 1, 0), float(2.0 * np.arctan(0.03 / dist)), w / h)
+        b.bvh(faces, b.lambertian(v3(0.8, 0.8, 0.8)), k_min=8)
+        b.sky()
+        res.append(b)
+    o, p = res
+    o_rgb, o_rays, _, o_total = o.render(h, w, spp, depth)
+    p.commit()
+    R = rtmi.Renderer(p, h, w, spp, depth).init_rng()
+    R.render()
+    img, cnt = R.untile()
+    torch.cuda.synchronize()
+    assert_same((img.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32), R.total_rays()), (o_rgb, o_rays, o_total))
