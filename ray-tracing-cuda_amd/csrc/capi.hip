@@ -455,6 +455,15 @@ int rtmi_scene_stats(const rtmi_scene *sp, int64_t out[8]) {
   return RTMI_OK;
 }
 
+int64_t rtmi_scene_sliver_faces(const rtmi_scene *sp) {
+  if (!sp) return fail(RTMI_ERR_INVALID, "null scene");
+  Scene tmp = *S(sp);
+  tmp.dev_allocs.clear();
+  std::string err = tmp.flatten();
+  if (!err.empty()) return fail(RTMI_ERR_INVALID, err);
+  return tmp.sliver_faces;
+}
+
 int64_t rtmi_scene_bytes_per_ray(const rtmi_scene *sp) {
   if (!sp) return fail(RTMI_ERR_INVALID, "null scene");
   Scene tmp = *S(sp);

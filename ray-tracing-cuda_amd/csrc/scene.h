@@ -67,6 +67,7 @@ struct Scene {
   std::vector<SphGroup> sph_groups;
   std::vector<SphMember> sph_members;
   float sph_mag = 0.f;
+  int64_t sliver_faces = 0;  // mesh faces with an interior angle below 1.4 degrees (rtmi_scene_sliver_faces)
   float list_mag = 0.f;
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;

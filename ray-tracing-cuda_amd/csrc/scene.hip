@@ -468,6 +468,7 @@ static int build_bvh_nodes(std::vector<BvhNode> &nodes, std::vector<FacePts> &fp
 std::string Scene::flatten() {
   pair_boxes.clear(), pair_pts.clear(), tri_nrm.clear(), list_mag = 0.f;
   sph_groups.clear(), sph_members.clear(), sph_mag = 0.f;
+  sliver_faces = 0;
   runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(), tops.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
@@ -573,6 +574,21 @@ std::string Scene::flatten() {
             fp[i].p[j] = mk(hb.faces[(size_t)i * 9 + j * 3], hb.faces[(size_t)i * 9 + j * 3 + 1],
                             hb.faces[(size_t)i * 9 + j * 3 + 2]);
           for (int j = 0; j < 6; j++) fp[i].uv[j] = has_uv ? hb.uvs[(size_t)i * 6 + j] : 0.f;
+          {  // smallest interior angle below the search margins' design limit (DESIGN.md "Mesh queries": ~1.4 degrees)?
+            const double P[3][3] = {{fp[i].p[0].x, fp[i].p[0].y, fp[i].p[0].z}, {fp[i].p[1].x, fp[i].p[1].y, fp[i].p[1].z},
+                                    {fp[i].p[2].x, fp[i].p[2].y, fp[i].p[2].z}};
+            double min_sin = 1.0;
+            for (int a = 0; a < 3; a++) {
+              const double *A = P[a], *B = P[(a + 1) % 3], *Cc = P[(a + 2) % 3];
+              const double u[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, v[3] = {Cc[0] - A[0], Cc[1] - A[1], Cc[2] - A[2]};
+              const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+              const double lu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), lv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+              const double sn = lu > 0 && lv > 0 ? std::sqrt(cx * cx + cy * cy + cz * cz) / (lu * lv) : 0.0;
+              // (an obtuse corner has a small sine too, but then one of the other two is acute and smaller)
+              min_sin = std::min(min_sin, sn);
+            }
+            if (min_sin < 0.0245) sliver_faces++;  // sin(1.4 degrees)
+          }
         }
         int leaf_max = hb.leaf_max > 0 ? hb.leaf_max : 2048;
         if (hb.n > leaf_max)

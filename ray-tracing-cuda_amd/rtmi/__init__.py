@@ -89,6 +89,7 @@ SYMBOLS = [
     ("rtmi_scene_commit", C.c_int, [C.c_void_p]),
     ("rtmi_scene_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     ("rtmi_scene_bytes_per_ray", C.c_int64, [C.c_void_p]),
+    ("rtmi_scene_sliver_faces", C.c_int64, [C.c_void_p]),
     ("rtmi_frame_work_items", C.c_int64, [_frp]),
     ("rtmi_frame_pixel_of", C.c_int64, [_frp, C.c_int64]),
     ("rtmi_frame_pixel_map", C.c_int, [_frp, C.POINTER(C.c_int64)]),
@@ -283,6 +284,9 @@ class SceneBuilder:
         _check(self.L.rtmi_scene_stats(self.h, out), "rtmi_scene_stats")
         keys = ["world", "spheres", "parallelograms", "triangles", "bvh_faces", "bvh_nodes", "materials", "textures"]
         return dict(zip(keys, list(out)))
+
+    def sliver_faces(self):
+        return _check(self.L.rtmi_scene_sliver_faces(self.h), "rtmi_scene_sliver_faces")
 
     def bytes_per_ray(self):
         return _check(self.L.rtmi_scene_bytes_per_ray(self.h), "rtmi_scene_bytes_per_ray")

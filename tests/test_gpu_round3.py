@@ -362,3 +362,63 @@ def test_far_false_accepts_outside_their_leaf_box(angle, dist):
     img, cnt = R.untile()
     torch.cuda.synchronize()
     assert_same((img.cpu().numpy(), cnt.cpu().numpy().astype(np.uint32), R.total_rays()), (o_rgb, o_rays, o_total))
+
+
+def far_view_world(seed):
+    """Third campaign of tools/gpu_fuzz.py: a small mesh seen from 10 .. 2e4 away, first or last in the world list,
+    fat or thin faces, reference leaves of 1 .. 64 faces.  Returns (fill, camera, h, w, spp, depth, description)."""
+    rng = np.random.default_rng(90000 + seed)
+    h, w = int(rng.integers(16, 49)), int(rng.integers(16, 65))
+    spp, depth = int(rng.integers(1, 4)), int(rng.choice([1, 3, 8]))
+    dist = float(10 ** rng.uniform(1, 4.3))
+    n = int(rng.choice([8, 64, 300]))
+    size = float(10 ** rng.uniform(-3.3, -1.5))
+    patch = float(rng.choice([0.01, 0.04, 0.2]))
+    thin = float(rng.choice([1.0, 0.1, 0.01]))
+    c = rng.uniform(-patch, patch, (n, 1, 3)) * np.array([1, 0.05, 1])
+    e = rng.uniform(-size, size, (n, 3, 3))
+    e[:, 2] = e[:, 1] * (1 - thin) + e[:, 2] * thin  # third corner close to the second: a sliver
+    faces = (c + e).astype(np.float32)
+    kmin = int(rng.choice([1, 2, 8, 64]))
+    mesh_first = bool(rng.integers(0, 2))
+    elev = float(rng.uniform(0.05, 1.4))
+    metal = seed % 3 == 0
+
+    def cam(b):
+        pos = v3(0.3 * dist * 0.01, dist * np.sin(elev), dist * np.cos(elev))
+        b.camera_pinhole(pos, v3(0, 0, 0), v3(0, 1, 0), float(2.0 * np.arctan(1.5 * patch / dist)), w / h)
+
+    def fill(b):
+        mat = b.metal(v3(0.9, 0.9, 0.9), 0.0) if metal else b.lambertian(v3(0.8, 0.8, 0.8))
+        if not mesh_first:
+            b.sky()
+        b.bvh(faces, mat, k_min=kmin)
+        if mesh_first:
+            b.sky()
+    probe = rtmi.SceneBuilder(1)
+    probe.camera_pinhole(v3(0, 0, 1), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+    probe.bvh(faces, probe.lambertian(v3(1, 1, 1)), k_min=kmin)
+    what = dict(dist=round(dist, 1), n=n, size=round(size, 5), thin=thin, kmin=kmin, mesh_first=mesh_first,
+                slivers=int(probe.sliver_faces()))
+    return fill, cam, h, w, spp, depth, what
+
+
+def test_far_views_and_the_documented_sliver_limit():
+    """Far-view worlds 0..299 of the fuzz campaign: bit for bit wherever the mesh has no face thinner than the search
+    margins' design limit (smallest angle >= 1.4 degrees, rtmi_scene_sliver_faces() == 0).  The four worlds the
+    3,000-world campaign of round 3 found differing (seeds 1527, 1674, 1675, 1774: 0.6-degree slivers of 6 .. 25 mm
+    seen from 60 .. 800 away, where the binary32 triangle test's false accepts reach further than the distance slack
+    of the search boxes) are flagged by rtmi_scene_sliver_faces and differ on a handful of pixels only -- the
+    documented limit of the exactness claim (include/rtmi.h)."""
+    for seed in range(300):
+        fill, cam, h, w, spp, depth, what = far_view_world(seed)
+        if what["slivers"]:
+            continue
+        g, o = render_pair(fill, h, w, spp, depth, post=False, seed=500 + seed, camera=cam)
+        assert g[2] == o[2] and np.array_equal(g[1], o[1]) and np.array_equal(g[0], o[0], equal_nan=True), (seed, what)
+    for seed in (1527, 1674, 1675, 1774):
+        fill, cam, h, w, spp, depth, what = far_view_world(seed)
+        assert what["slivers"] > 0, (seed, what)
+        g, o = render_pair(fill, h, w, spp, depth, post=False, seed=500 + seed, camera=cam)
+        differing = (g[1] != o[1]) | (g[0] != o[0]).any(axis=2)
+        assert differing.mean() <= 0.02, (seed, what, int(differing.sum()))

@@ -92,3 +92,25 @@ if len(sys.argv) > 3:
             bad += 1
             print("SOUP MISMATCH seed", seed, h, w, spp, depth, [(s[0].shape[0], s[1], s[2]) for s in soups], flush=True)
     print("soup seeds %d..%d: %d mismatches, %.1fs" % (first, first + int(sys.argv[3]) - 1, bad, time.time() - t0), flush=True)
+
+# ---- third campaign: small meshes seen from far away (tests/test_gpu_round3.py: far_view_world), the regime of
+# binary32 false accepts outside the leaves' exact boxes; worlds with faces below the margins' 1.4-degree design limit
+# (rtmi_scene_sliver_faces) are counted apart
+if len(sys.argv) > 4:
+    import test_gpu_round3 as t3
+    bad = bad_sliver = n_sliver = 0
+    t0 = time.time()
+    for seed in range(first, first + int(sys.argv[4])):
+        fill, cam, h, w, spp, depth, what = t3.far_view_world(seed)
+        g, o = t3.render_pair(fill, h, w, spp, depth, post=False, seed=500 + seed, camera=cam)
+        slivers = what["slivers"]
+        n_sliver += slivers > 0
+        ok = g[2] == o[2] and np.array_equal(g[1], o[1]) and np.array_equal(g[0], o[0], equal_nan=True)
+        if not ok:
+            if slivers:
+                bad_sliver += 1
+            else:
+                bad += 1
+            print("FAR MISMATCH seed", seed, h, w, spp, depth, what, flush=True)
+    print("far-view seeds %d..%d: %d mismatches in worlds without sliver faces, %d in the %d worlds with them, %.1fs" %
+          (first, first + int(sys.argv[4]) - 1, bad, bad_sliver, n_sliver, time.time() - t0), flush=True)
