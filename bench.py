@@ -450,6 +450,16 @@ def main():
                 extras.append(extra_line(tag, wx, rx, nx, sh))
         if rank == 0:
             out["config"]["extra"] = extras
+        # what an 8-GPU node can reach on the N > 1 workload (C4), measured on this one GPU: full frame against each
+        # of the eight shards (kernel only; the N-rank step adds one gather of ~6 MB per rank and the untile kernel)
+        sw = shard_sweep(rtmi, torch, dict(WORKLOADS["c4"], name="c4"), 8, args)
+        if rank == 0:
+            out["config"]["shard_sweep"] = {
+                "workload": sw["workload"], "G": sw["G"], "full_frame_kernel_ms": sw["full_frame"]["kernel_ms"],
+                "shard_kernel_ms": [round(x["kernel_ms"], 2) for x in sw["shards"]],
+                "predicted_speedup": sw["predicted_speedup"], "pixels_per_lane_per_shard": sw["shards"][0]["pixels_per_lane"],
+                "gather_bytes_per_rank": sw["shards"][0]["gather_bytes"], "ray_total_matches": sw["ray_total_matches"],
+                "note": sw["note"]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
