@@ -174,10 +174,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                 float4 qa, qb, qc, qd;
                 if (s_pairs != nullptr) {  // (wave-uniform) staged in LDS
                   const float4 *pp = s_pairs + pidx;
-                  qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                  qa = load_lds<float4>(pp), qb = load_lds<float4>(pp + 1), qc = load_lds<float4>(pp + 2), qd = load_lds<float4>(pp + 3);
                 } else {  // a list too long for the staging: per-lane gather of 64 bytes (L1 / L2 resident)
                   const float4 *pp = reinterpret_cast<const float4 *>(sc.pair_pts) + pidx;
-                  qa = pp[0], qb = pp[1], qc = pp[2], qd = pp[3];
+                  qa = load_global<float4>(pp), qb = load_global<float4>(pp + 1), qc = load_global<float4>(pp + 2), qd = load_global<float4>(pp + 3);
                 }
                 const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
                 float ta = 0.f, ua = 0.f, va = 0.f, tb = 0.f, ub = 0.f, vb = 0.f;

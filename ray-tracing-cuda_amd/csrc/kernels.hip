@@ -436,6 +436,7 @@ static bool plain_list_scan() {
 static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &fr, int threads, size_t *lds_bytes,
                           bool mats_in_lds = true) {
   LaunchCfg lc{};
+  lc.threads = threads;
   lc.tile_order = nullptr;
   lc.lds_mats = mats_in_lds && sc.n_mats <= kLdsMats ? sc.n_mats : 0;
   lc.wide_ids = sc.n_mats > 256 ? 1 : sc.n_mats <= 16 ? 2 : 0;

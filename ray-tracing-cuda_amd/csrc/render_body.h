@@ -21,7 +21,7 @@ struct LaunchCfg {
   int32_t list_off;    // byte offset of the per-wave regions of the shared candidate tests, -1: each lane tests its own
   int32_t paths_off;   // byte offset of the staged leaf-path words
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
-  int32_t pad2;
+  int32_t threads;     // lanes per workgroup (== blockDim.x)
   int32_t nrm_off;     // byte offset of the staged TriNrm records (with pairs_off), -1: not staged
   int32_t cand_off;    // byte offset of the per-lane candidate slots of the grouped sphere scan, -1: none
   const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
@@ -40,10 +40,14 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   MatRec *s_mats = reinterpret_cast<MatRec *>(smem);
   // id stack: byte offset of entry [level][thread] in LDS, kept as 32-bit arithmetic (pointer
   // arithmetic on the generic pointers costs a register pair per live address)
+  // lanes per workgroup, from the kernel arguments: blockDim.x is a 16-bit field of the dispatch packet, which the
+  // compiler reads with a VECTOR load (global_load_ushort + s_waitcnt vmcnt(0)) at every use inside the loop --
+  // three round trips to memory per iteration before round 3
+  const uint32_t n_threads = (uint32_t)lc.threads;
   const uint32_t ids_shift = lc.wide_ids == 1 ? 1u : 0u;
   const bool nibble_ids = lc.wide_ids == 2;
   auto ids_offset = [&](int level) -> uint32_t {  // (nibble_ids: the byte of levels 2k and 2k + 1 is row k)
-    return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << ids_shift);
+    return (uint32_t)lc.stack_off + (((uint32_t)level * n_threads + threadIdx.x) << ids_shift);
   };
   const BvhNode *s_nodes = reinterpret_cast<const BvhNode *>(smem + lc.nodes_off);
   int *wl = nullptr;  // this wave's mesh-search region
@@ -71,7 +75,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
             __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (64 * kSphCand + 128);  // slots + 64 counters
   const bool mats_in_lds = lc.lds_mats > 0;
   auto lds_rgb = [&](int m) -> V3 {  // a staged material's colour: one 16-byte read (MatRec: r, g, b, kind)
-    const float4 c = *reinterpret_cast<const float4 *>(s_mats + m);
+    const float4 c = load_lds<float4>(s_mats + m);
     return mk(c.x, c.y, c.z);
   };
   const bool fast_fold = mats_in_lds && lc.wide_ids != 1 && sc.unsigned_colours;  // see the radiance fold
@@ -117,7 +121,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   // shard, 43 % of the waves' time spent waiting.)  Image-textured scenes: a layer is one 32-bit word in LDS,
   // [level][thread] -- the material id, or bit 31 + the sampled texel's three bytes (trace_helpers.h: tex_fetch).
   auto tex_layer_offset = [&](int level) -> uint32_t {
-    return (uint32_t)lc.stack_off + (((uint32_t)level * (uint32_t)blockDim.x + threadIdx.x) << 2);
+    return (uint32_t)lc.stack_off + (((uint32_t)level * n_threads + threadIdx.x) << 2);
   };
 
   // Mesh variants, frames dominated by a few outlier tiles (their pixels bounce to the depth limit
@@ -421,7 +425,17 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               tv = (tc[1] * w + tc[3] * h.u) + tc[5] * h.v;
             }
           }
-          const MatRec m = mats_in_lds ? s_mats[mat] : sc.mats[mat];
+          MatRec m;  // r, g, b, kind | param, tex (the padding is not read)
+          {
+            float4 m0;
+            float2 m1;
+            if (mats_in_lds) {  // (wave-uniform)
+              m0 = load_lds<float4>(s_mats + mat), m1 = load_lds<float2>(reinterpret_cast<const char *>(s_mats + mat) + 16);
+            } else {
+              m0 = load_global<float4>(sc.mats + mat), m1 = load_global<float2>(reinterpret_cast<const char *>(sc.mats + mat) + 16);
+            }
+            m.r = m0.x, m.g = m0.y, m.b = m0.z, m.kind = __float_as_int(m0.w), m.param = m1.x, m.tex = __float_as_int(m1.y);
+          }
           V3 rgb = mk(m.r, m.g, m.b);
           RTMI_STAT2(if (!(F & F_BVH)) { const unsigned long long tsa = stat_now();  // (divergent code: first active lane reports)
             if ((int)(threadIdx.x & 63u) == __builtin_ctzll(__ballot(1))) g_wave_stats[((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 16383u][9] += tsa - tq2; })
@@ -501,7 +515,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         if (!(F & F_TEX) && fast_fold) {
           // common case (byte ids, material table in LDS, no signed colours) without the per-layer
           // uniform branches: four layers at a time, ids first, then colours, then the products
-          const uint32_t step = blockDim.x;
+          const uint32_t step = n_threads;
           if (nibble_ids) {
             if (i >= 0 && !(i & 1)) {  // an even top level sits alone in the low half of its byte
               const int m0 = smem[ids_offset(i >> 1)] & 15;

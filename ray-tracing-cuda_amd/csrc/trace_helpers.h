@@ -207,6 +207,34 @@ __device__ __forceinline__ void cull_step_nlt(uint32_t &mask, float a, float b) 
   asm("v_cmp_nlt_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(a), "v"(b) : "vcc");
 }
 
+// Loads whose address space is spelt out.  `staged ? lds_pointer : global_pointer` followed by one load makes the
+// compiler select the POINTER and issue a flat load (which takes the vector-memory path even for LDS data and
+// waits on both counters); with the address spaces in the types the two branches stay a ds_read and a global_load.
+#define RT_LDS __attribute__((address_space(3)))
+#define RT_GLOBAL __attribute__((address_space(1)))
+typedef float rt_f32x4 __attribute__((ext_vector_type(4)));
+typedef float rt_f32x2 __attribute__((ext_vector_type(2)));
+template <typename V>
+struct LoadAs;
+template <>
+struct LoadAs<float4> {
+  typedef rt_f32x4 raw;
+  static __device__ __forceinline__ float4 cvt(raw v) { return make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <>
+struct LoadAs<float2> {
+  typedef rt_f32x2 raw;
+  static __device__ __forceinline__ float2 cvt(raw v) { return make_float2(v[0], v[1]); }
+};
+template <typename V>
+__device__ __forceinline__ V load_lds(const void *p) {
+  return LoadAs<V>::cvt(*(const RT_LDS typename LoadAs<V>::raw *)p);
+}
+template <typename V>
+__device__ __forceinline__ V load_global(const void *p) {
+  return LoadAs<V>::cvt(*(const RT_GLOBAL typename LoadAs<V>::raw *)p);
+}
+
 // World-list triangle records are read through the constant address space: a
 // wave-uniform address there always selects scalar loads (one s_load_dwordx16 per
 // record into SGPRs) instead of per-lane vector loads.
