@@ -319,12 +319,12 @@ static int collapse4(std::vector<QNode4> &qn, const std::vector<BinNode> &bn, in
     int e = -60;
     if (extent > 0) e = (int)std::ceil(std::log2(extent / 255.0));
     e = e < -60 ? -60 : e > 100 ? 100 : e;
-    for (;;) {  // the far corner must land on the grid
+    for (; e < 127; e++) {  // the far corner must land on the grid (finite bounds: rtmi_add_bvh refuses others,
+                            // and the loop is bounded in any case: an int8 exponent is all a node can hold)
       bool fits = true;
       for (int c = 0; c < nk; c++)
-        if (std::ceil(std::ldexp((double)cmx[c][a] - (double)lo, -e)) > 255.0) fits = false;
+        if (!(std::ceil(std::ldexp((double)cmx[c][a] - (double)lo, -e)) <= 255.0)) fits = false;
       if (fits) break;
-      e++;
     }
     nd.exp[a] = (int8_t)e;
     for (int c = 0; c < 4; c++) {
