@@ -74,7 +74,7 @@ static bool all_finite(const float *p, size_t n) {
 
 static bool make_frame(const rtmi_frame *f, FrameDev *out) {
   if (!f || f->height <= 0 || f->width <= 0 || f->spp < 0 || f->world_size <= 0 || f->rank < 0 ||
-      f->rank >= f->world_size)
+      f->rank >= f->world_size || f->height > 65535 || f->width > 65535)  // (a pixel's row and column share a word)
     return false;
   FrameDev d;
   d.height = f->height, d.width = f->width, d.spp = f->spp, d.max_depth = f->max_depth, d.post = f->post_process;

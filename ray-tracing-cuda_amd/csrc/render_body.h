@@ -102,12 +102,13 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   const bool f32_jitter = w_pow2 && h_pow2 && fr.width <= (1 << 20) && fr.height <= (1 << 20);  // (wave-uniform)
   // per-lane pixel state
   int32_t q32 = 0;  // the lane's work item (items < 2^31: make_frame); widened where it addresses memory
-  int pi = 0, pj = 0, k = 0;
+  uint32_t ray_acc = 0;  // closest-hit queries of this lane's finished pixels, modulo what it has flushed (below)
+  uint32_t pij = 0;  // the pixel's row << 16 | column (frames are below 65536 x 65536: make_frame)
+  int k = 0;
   bool has_px = false, done = false, active = false;
   bool heavy = false;  // a pixel of the queue's sparse head (see below)
   V3 color = splat(0.f);
   uint32_t rays = 0;
-  unsigned long long ray_total = 0;
   Rng rng = {0, 0, 0, 0, 0, 0};
   // per-lane path state
   V3 o = splat(0.f), d = splat(0.f);
@@ -151,8 +152,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       if (ray_counts) ray_counts[q] = 0;
       return false;
     }
-    pi = (int)(idx / fr.width);
-    pj = (int)(idx % fr.width);
+    pij = ((uint32_t)(idx / fr.width) << 16) | (uint32_t)(idx % fr.width);
     rng.d = states[0 * n_items + q];
     rng.v0 = states[1 * n_items + q];
     rng.v1 = states[2 * n_items + q];
@@ -186,7 +186,13 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       out[q * 3 + 1] = c.y;
       out[q * 3 + 2] = c.z;
       if (ray_counts) ray_counts[q] = rays;
-      ray_total += rays;
+      // the lane's ray total in ONE register: 2^31 at a time goes to the global counter (a constant addend: the
+      // compiler's wave-level combining of atomics needs no scan for it), the rest at the end of the kernel
+      ray_acc += rays;
+      if (ray_acc >= 0x80000000u) {
+        atomicAdd(&counters[1], 0x80000000ull);
+        ray_acc -= 0x80000000u;
+      }
       states[0 * n_items + q] = rng.d;
       states[1 * n_items + q] = rng.v0;
       states[2 * n_items + q] = rng.v1;
@@ -278,11 +284,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           // final (float)x of the exact (u + j) / W; and rounding commutes with a power-of-two scaling, so that
           // is RN(u + j) * (1 / W): one binary32 addition (correctly rounded sum of two binary32 numbers) and an
           // exact multiplication.  (tests/test_host_logic.py::test_jitter_in_binary32_for_power_of_two_frames)
-          xf = (r1 + (float)pj) * (float)inv_w;
-          yf = (r2 + (float)(fr.height - pi)) * (float)inv_h;
+          xf = (r1 + (float)(pij & 0xffffu)) * (float)inv_w;
+          yf = (r2 + (float)(fr.height - (int)(pij >> 16))) * (float)inv_h;
         } else {
-          double x = (double)r1 + (double)pj;
-          double y = (double)r2 + (double)(fr.height - pi);
+          double x = (double)r1 + (double)(int)(pij & 0xffffu);
+          double y = (double)r2 + (double)(fr.height - (int)(pij >> 16));
           // division by a power of two is an exact scaling: multiply by the (exact) reciprocal
           x = w_pow2 ? x * inv_w : x / (double)fr.width;
           y = h_pow2 ? y * inv_h : y / (double)fr.height;
@@ -589,9 +595,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(st.cyc[4] += stat_now() - tq2;)
   }
 
-  // total closest-hit queries: wave reduce, one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) ray_total += __shfl_down(ray_total, off);
-  if ((threadIdx.x & 63) == 0 && ray_total) atomicAdd(&counters[1], ray_total);
+  {  // total closest-hit queries: wave reduce, one atomic per wave
+    unsigned long long ray_total = ray_acc;
+    for (int off = 32; off > 0; off >>= 1) ray_total += __shfl_down(ray_total, off);
+    if ((threadIdx.x & 63) == 0 && ray_total) atomicAdd(&counters[1], ray_total);
+  }
 #ifdef RTMI_STATS
   if ((threadIdx.x & 63) == 0) {
     const unsigned v[13] = {wave_queries, st.searches, st.node_steps, st.face_steps, st.nodes_popped, st.blocks_popped,
