@@ -19,7 +19,7 @@ b = rtmi.SceneBuilder(10086); scenes.bunny(b, 1.0, scenes.procedural_bunny_mesh(
 R = rtmi.Renderer(b, 1024, 1024, spp, 10).init_rng()
 bpc = int(os.environ.get("RTMI_TOOL_BPC", "0"))
 R.render(opts=rtmi.render_opts(blocks_per_cu=bpc) if bpc else None); torch.cuda.synchronize()
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 40)()
 rtmi.lib().rtmi_debug_counters(b.h, out, None)
 names = ["queue", "rays", "abandoned", "-", "wave_queries", "searches", "node_steps", "face_steps", "nodes_popped",
          "blocks_popped", "insert_rounds", "hist<=1", "hist<=4", "hist<=8", "hist<=12", "hist<=20", "hist>20",
