@@ -422,3 +422,24 @@ def test_far_views_and_the_documented_sliver_limit():
         g, o = render_pair(fill, h, w, spp, depth, post=False, seed=500 + seed, camera=cam)
         differing = (g[1] != o[1]) | (g[0] != o[0]).any(axis=2)
         assert differing.mean() <= 0.02, (seed, what, int(differing.sum()))
+
+
+def test_bench_shard_and_sweep_paths():
+    """bench.py --shard r/G and --shard-sweep G on a small workload: the one-GPU estimate of G-GPU strong scaling (each
+    shard rendered as rank r of G would render it).  The shards' ray totals add up to the full frame's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--shard-sweep", "2"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sw = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["shard_sweep"]
+    assert sw["G"] == 2 and len(sw["shards"]) == 2 and sw["ray_total_matches"] and sw["predicted_speedup"] > 0
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--shard", "1/2", "--steps", "2",
+                        "--no-extra", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and "shard 1 only" in line["config"]["workload"] and line["value"] > 0
