@@ -121,8 +121,50 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         if (!live) mask = 0u;  // a lane without a ray of its own only helps
         RTMI_STAT2(const unsigned long long tc1 = stat_now(); st.cyc[5] += tc1 - tc0;)
         RTMI_STAT(st.cull_bits += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true)) * 0u; { unsigned pc = __builtin_popcount(mask); for (int off = 32; off > 0; off >>= 1) pc += __shfl_down(pc, off); st.cull_bits += __builtin_amdgcn_readfirstlane(pc); } st.cull_rays += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(true));)
+#ifndef RTMI_OWN_FIRST
+#define RTMI_OWN_FIRST 1
+#endif
+#if RTMI_OWN_FIRST
+        // ---- a lane's FIRST candidate of the chunk needs no hand-over: nearly every ray has one (the surface it
+        // starts on, or the one it hits), so this round of tests is as full as a round of shared tasks, and the ray
+        // is in the lane's own registers -- no task word, no ray record, no result words for it.  Its test sees the
+        // lane's running t_to directly, as the reference's does (utils.cu:74).
+        if (__builtin_amdgcn_ballot_w64(mask != 0u) != 0ull) {
+          if (mask != 0u) {
+            const int bit = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            const size_t pidx = (size_t)(pair0 + c0 + bit) * 4;
+            float4 qa, qb, qc, qd;
+            if (s_pairs != nullptr) {  // (wave-uniform) staged in LDS
+              const float4 *pp = s_pairs + pidx;
+              qa = load_lds<float4>(pp), qb = load_lds<float4>(pp + 1), qc = load_lds<float4>(pp + 2), qd = load_lds<float4>(pp + 3);
+            } else {
+              const float4 *pp = reinterpret_cast<const float4 *>(sc.pair_pts) + pidx;
+              qa = load_global<float4>(pp), qb = load_global<float4>(pp + 1), qc = load_global<float4>(pp + 2), qd = load_global<float4>(pp + 3);
+            }
+            const V3 p0 = mk(qa.x, qa.y, qa.z), p1 = mk(qa.w, qb.x, qb.y), p2 = mk(qb.z, qb.w, qc.x), p3 = mk(qc.y, qc.z, qc.w);
+            float ta = 0.f, ua = 0.f, va = 0.f, tb = 0.f, ub = 0.f, vb = 0.f;
+            const V3 e1 = p1 - p0, e2 = p2 - p0;
+            const bool hit_a = tri_test_flat<T>(p0, e1, e2, cross3(d, e2), o, d, t_to, ta, ua, va, det_safe);
+            bool hit_b = false;
+            if (__float_as_int(qd.x) & PAIR_SECOND) {
+              const V3 e1b = p2 - p1, e2b = p3 - p1;
+              hit_b = tri_test_flat<T>(p1, e1b, e2b, cross3(d, e2b), o, d, t_to, tb, ub, vb, det_safe) && !hit_a;  // parallelogram.cu:33
+            }
+            const float t = hit_a ? ta : tb;
+            const bool acc = (hit_a || hit_b) && (!ok || (T)t < t_to);
+            ok = ok || acc;
+            t_to = acc ? (T)t : t_to;
+            win = acc ? make_id(RUN_TRIS, run.first + 2 * (c0 + bit) + (hit_a ? 0 : 1)) : win;
+            if (F & F_TEX) {
+              bu = acc ? (hit_a ? ua : ub) : bu;
+              bv = acc ? (hit_a ? va : vb) : bv;
+            }
+          }
+        }
+#endif
         {
-          // ---- the candidates of all 64 rays are worked off by all 64 lanes.  A ray comes near 2.2 pairs on
+          // ---- the (remaining) candidates of all 64 rays are worked off by all 64 lanes.  A ray comes near 2.2 pairs on
           // average but the unluckiest of 64 near 6, and a lane-by-lane loop runs as long as that one.  So
           // (a) every lane writes its ray and one task per candidate pair to LDS (offsets: prefix sum of the
           // candidate counts by bit planes), (b) lane l takes task l, l + 64, ...: reads that ray and that
