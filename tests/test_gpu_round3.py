@@ -443,3 +443,38 @@ def test_bench_shard_and_sweep_paths():
     assert r.returncode == 0, r.stdout + r.stderr
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert line["n_gpus"] == 1 and "shard 1 only" in line["config"]["workload"] and line["value"] > 0
+
+
+def test_everything_at_once_variant():
+    """A world that needs every kernel feature together (the F_ALL specialisation): a grouped sphere run, world-list
+    pairs, two meshes (one with texture coordinates under an image texture), a defocus camera."""
+    from rtmi import scenes
+
+    def cam(b):
+        b.camera_defocus(v3(0, 1.2, 3.2), v3(0, 0.6, -1), v3(0, 1, 0), PI_D / 3, 48 / 36, 0.08, 4.0)
+
+    def fill(b):
+        rng = np.random.default_rng(12)
+        mats = [b.lambertian(v3(*rng.uniform(0.2, 0.9, 3))) for _ in range(3)] + [b.metal(v3(0.9, 0.9, 0.9), 0.05), b.dielectric(v3(1, 1, 1), 1.5)]
+        tex = b.lambertian_tex(b.image_texture(scenes.procedural_earthmap(32, 64)))
+        b.parallelogram([v3(-4, 0, -6), v3(4, 0, -6), v3(-4, 0, 2)], mats[0])
+        for _ in range(40):
+            b.sphere(v3(rng.uniform(-2.5, 2.5), rng.uniform(0.1, 1.8), rng.uniform(-4, 0.5)), float(rng.uniform(0.05, 0.3)),
+                     mats[int(rng.integers(0, 5))])
+        b.sphere(v3(1.2, 0.5, -0.5), 0.5, tex)
+        for k in range(5):
+            b.parallelepiped([v3(-2 + k, 0, -2.5), v3(-1.6 + k, 0, -2.5), v3(-2 + k, 0.5, -2.5), v3(-2 + k, 0, -2.1)], mats[k % 5])
+        n = 60
+        base = rng.uniform(-0.5, 0.5, (n, 1, 3)) + np.array([-1.0, 0.8, -1.5])
+        faces = (base + rng.uniform(-0.2, 0.2, (n, 3, 3))).astype(np.float32)
+        uvs = rng.uniform(0, 1, (n, 6)).astype(np.float32)
+        b.bvh(faces, tex, uvs=uvs, k_min=8)
+        b.bvh((faces + np.float32(1.5)).astype(np.float32), mats[3], k_min=2)
+        b.parallelogram([v3(-1, 3.2, -3), v3(1, 3.2, -3), v3(-1, 3.2, -1)], b.diffuse_light(b.constant_texture(v3(3, 3, 3))))
+        b.sky()
+    g, o = render_pair(fill, 36, 48, 3, 10, camera=cam)
+    # the image-textured sphere's texel choice goes through acosf / atan2f (two libms): the north-star tolerance there
+    assert g[2] == o[2] or abs(g[2] - o[2]) <= 4
+    rel = np.sqrt(((g[0].astype(np.float64) - o[0]) ** 2).sum() / (o[0].astype(np.float64) ** 2).sum())
+    assert rel <= 1e-3, rel
+    assert (g[1] == o[1]).mean() > 0.99
