@@ -56,6 +56,8 @@ static RenderTuning default_tuning() {
     g_tune.outlier_x10 = env_int("RTMI_OUTLIER_X10", 20);
     if (g_tune.outlier_x10 < 1) g_tune.outlier_x10 = 20;
     g_tune.head_pct[0] = 80, g_tune.head_pct[1] = 55, g_tune.head_pct[2] = 30;
+    g_tune.promote = env_int("RTMI_PROMOTE", 16);  // samples after which a pixel's own ray count may promote it (0: never)
+    if (g_tune.promote < 0) g_tune.promote = 0;
     g_tune.probe_spp = env_int("RTMI_PROBE_SPP", 0);
     if (g_tune.probe_spp < 0 || g_tune.probe_spp > 64) g_tune.probe_spp = 0;
   });
@@ -551,12 +553,14 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 
 // ------------------------------------------------------------------ render
 // Per-call scratch: [ counters: RTMI_COUNTER_WORDS x 8 B ][ probe RNG states ][ probe ray counts ][ tile costs ]
-// [ tile order ][ 32 words of scheduler meta ][ head list: kHeadCap words ].  The counters come first so that
+// [ tile order ][ 32 words of scheduler meta ][ head list: kHeadCap words ][ probe work counts ][ quarter costs ]
+// [ quarters sorted ][ quarter order ][ 4 words ].  The counters come first so that
 // rtmi_render_status can find them from the scratch pointer alone.
 static constexpr size_t kCounterBytes = RTMI_COUNTER_WORDS * sizeof(unsigned long long);
 static size_t scratch_bytes_of(const FrameDev &d) {
   const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-  return kCounterBytes + n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4;
+  return kCounterBytes + n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4 +
+         n * 4 + nt * 4 * 12 + 16;  // + the probe's work counts, the quarter-tile costs, their sorted list, the order
 }
 size_t rtmi_render_scratch_bytes(const rtmi_frame *f) {
   FrameDev d;
@@ -709,12 +713,22 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_cost = p_rays + n;
     uint32_t *p_order = p_cost + nt;
     uint32_t *p_meta = p_order + nt;  // 16 + 16 words (launch_tile_order); 450 * nt words in: 8-byte aligned
+    uint32_t *p_work = p_meta + 32 + kHeadCap;
+    uint32_t *p_qcost = p_work + n, *p_qsorted = p_qcost + 4 * nt, *p_qmap = p_qsorted + 4 * nt, *p_qmax = p_qmap + 4 * nt;
+    // mesh frames (binary32 t): the probe also books the lane-steps of its mesh searches on the pixels they serve
+    static const bool cost_probe = env_int("RTMI_COST_PROBE", 1) != 0;
+    const bool by_cost = cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
     HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
     probe.spp = probe_spp;
     HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
     // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
-    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, counters, SchedPlan(), true, blocks,
+    SchedPlan probe_plan;
+    if (by_cost) {
+      HIP_TRY(hipMemsetAsync(p_work, 0, n * 4, st));
+      probe_plan.visit_counts = p_work;
+    }
+    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, counters, probe_plan, true, blocks,
                           threads, tune, st));
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
     // the head of a mesh frame's queue: pixels in weight classes (the default), or -- when the call names a
@@ -724,10 +738,14 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_head = (variant & F_BVH) && by_pixels ? p_meta + 32 : nullptr;
     HIP_TRY(launch_tile_order(p_rays, d.local_tiles, p_cost, p_meta, p_order, p_head, sparse_cap, blocks * (threads / 64),
                               tune.outlier_x10, tune.head_pct, st));
-    plan.tile_order = p_order;
+    // (the head's marks in p_rays are bit 31: quarter_cost_kernel masks them off)
+    HIP_TRY(launch_quarter_order(p_order, by_cost && by_pixels ? p_work : nullptr, p_rays, d.local_tiles, p_qcost, p_qsorted, p_qmax,
+                                 p_qmap, st));
+    plan.tile_order = p_qmap;
     plan.sparse_items = p_meta + 1;
     plan.head_list = p_head;
     plan.probe_marks = p_head ? p_rays : nullptr;
+    plan.probe_spp = probe_spp;
   }
   HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts, counters,

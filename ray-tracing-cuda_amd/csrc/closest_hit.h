@@ -12,7 +12,7 @@
 template <uint32_t F>
 __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_nodes, int lds_nodes, const int *s_paths,
                                            int lds_paths, const float4 *s_pairs, int *ll, uint16_t *cands, int *wl,
-                                           unsigned long long *overflow, V3 o, V3 d, bool live
+                                           unsigned long long *overflow, V3 o, V3 d, bool live, bool count_work
 #ifdef RTMI_STATS
                                            , MeshStats &st
 #endif
@@ -23,6 +23,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   T t_to = (T)INFINITY;
   uint32_t win = ID_NONE;
   int32_t aux = 0;
+  int32_t work = 0;
   float bu = 0.f, bv = 0.f;
 
   double sa = 0.0, sa2 = 0.0;
@@ -595,17 +596,36 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         uint32_t prev_code = 0u, entered = 0u;
         uint32_t lo_code = 0u;
         bool need = live;
+#ifndef RTMI_MESH_PRETEST
+#define RTMI_MESH_PRETEST 1
+#endif
+#if RTMI_MESH_PRETEST
+        // A ray that stays clear of the mesh's bounds needs no search (and a wave of such rays -- most of a frame is
+        // background -- skips search and replay altogether): when the reference tree has inner nodes, a face only
+        // counts if the ray crosses the exact box of a child of the root (bvh.cuh:138-150), which lies inside the
+        // root's.  The root's bounds are padded far beyond what that binary32 test can get wrong.  (A mesh whose root is
+        // a leaf has no box test at all: every face the triangle test accepts counts, from however far off.)
+        if (br.ref_depth > 0) {
+          const f32x8 rb = *(const RT_CONSTANT f32x8 *)(uintptr_t)(sc.nodes + br.root);
+          BvhNode rn;
+          rn.mn[0] = rb[0], rn.mn[1] = rb[1], rn.mn[2] = rb[2], rn.mx[0] = rb[3], rn.mx[1] = rb[4], rn.mx[2] = rb[5];
+          const float diag = fmaxf(fmaxf(rb[3] - rb[0], rb[4] - rb[1]), rb[5] - rb[2]);
+          const float pad = 1e-3f * diag + 1e-4f * br.mag + 0x1p-15f * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + br.mag);
+          need = need && slab_touch(rn, pad, o, inv_d, T_FROM_F * 0.999f, (float)bt_to * 1.0001f + 1e-6f);
+        }
+#endif
         // All 64 lanes walk this loop together (lanes without a ray with need == false): the search
         // is the wave's.
         while (__ballot(need) != 0ull) {
           // ---- (1) search: best face per leaf with lo_code <= code < cut, t <= bt_to
           RTMI_STAT(const unsigned long long ts0 = stat_now();)
           mesh_search<T, DT>(sc, br.sub_root, sc.tops + (size_t)(run.first + i) * kTopEntries, br.mag, wl, need, o, d, inv_d,
-                             bt_to, lo_code, overflow
+                             bt_to, lo_code, overflow, count_work
 #ifdef RTMI_STATS
                              , st
 #endif
           );
+          if (!DT && count_work && need) work += rr[7];
           RTMI_STAT(const unsigned long long ts1 = stat_now(); st.cyc[2] += ts1 - ts0;)
           // ---- (2) replay the listed leaves in the reference's visiting order.  The box tests are
           // spread over the wave: AABB::Hit(box, [t_from, T]) is `crossing time <= T` with a crossing time
@@ -792,5 +812,6 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   h.aux = aux;
   h.u = bu;
   h.v = bv;
+  h.work = work;
   return h;
 }

@@ -33,14 +33,17 @@ struct RenderTuning {
   int head_pct[3];    // mesh frames: per cent of the frame's largest probe count from which a pixel gets a wave to itself,
                       // shares one with another, gets one lane in 16 (80 / 55 / 30)
   int probe_spp;      // samples per pixel of the scheduler's cost probe; 0: chosen per frame (capi.hip)
+  int promote;        // 1: mesh frames promote pixels to a head class at run time
 };
 // What the scheduler's probe pass leaves for the real pass (device pointers, all optional).
 struct SchedPlan {
-  const uint32_t *tile_order = nullptr;    // local tiles, most expensive first
+  const uint32_t *tile_order = nullptr;    // the queue's order per quarter tile (launch_quarter_order)
+  uint32_t *visit_counts = nullptr;        // probe pass of a mesh frame: receives per work item the lane-steps of its searches
   const uint32_t *sparse_items = nullptr;  // one word: leading work items handed to every sparse_stride-th lane only
                                            // (with head_list: + [1], [2] = ends of its 64- and 32-lane classes)
   const uint32_t *head_list = nullptr;     // optional: the head's work items, heaviest pixels first (kHeadCap words)
   const uint32_t *probe_marks = nullptr;   // with head_list: per work item, bit 31 set = listed in the head
+  int probe_spp = 2;                       // samples per pixel of the probe behind these (thresholds: sparse_items[23..25])
 };
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan, bool probe,
@@ -55,6 +58,12 @@ constexpr int kHeadCap = 16384;
 hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
                              const int head_pct[3], hipStream_t stream);
+
+// The per-quarter-tile order the trace kernel's queue follows (4 * n_tiles words): d_order's tiles with their quarters in
+// sequence, or -- d_work != nullptr: mesh frames with a cost probe -- the quarters sorted by probed cost and dealt to the
+// 64-item blocks in a snake (kernels.hip).  d_qcost / d_qsorted: 4 * n_tiles words of scratch each, d_qmax one word.
+hipError_t launch_quarter_order(const uint32_t *d_order, const uint32_t *d_work, const uint32_t *d_rays, int n_tiles,
+                                uint32_t *d_qcost, uint32_t *d_qsorted, uint32_t *d_qmax, uint32_t *d_qmap, hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);

@@ -314,6 +314,73 @@ __global__ __launch_bounds__(256) void head_scatter_kernel(uint32_t *__restrict_
   }
 }
 
+// The queue's order is kept per QUARTER tile (16 work items = two rows of a tile).  List scenes: the tiles in
+// longest-first order, each tile's quarters one after the other.
+__global__ __launch_bounds__(256) void expand_order_kernel(const uint32_t *__restrict__ order, int n_tiles,
+                                                            uint32_t *__restrict__ qmap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_tiles * 4) qmap[i] = order[i >> 2] * 4u + (uint32_t)(i & 3);
+}
+// Mesh scenes with a cost probe: a quarter's cost = the lane-steps the probe's mesh searches spent on its 16 pixels
+// (+ their ray counts, so that it is never zero) ...
+__global__ __launch_bounds__(256) void quarter_cost_kernel(const uint32_t *__restrict__ work, const uint32_t *__restrict__ rays,
+                                                            int n_quarters, uint32_t *__restrict__ cost,
+                                                            uint32_t *__restrict__ max_cost) {
+  const int qd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qd >= n_quarters) return;
+  uint32_t s = 0;
+  for (int i = 0; i < 16; i++) s += work[(size_t)qd * 16 + i] + (rays[(size_t)qd * 16 + i] & 0x7fffffffu);
+  cost[qd] = s;
+  atomicMax(max_cost, s);
+}
+// ... one workgroup sorts the quarters by cost (256 buckets, dearest first) ...
+__global__ __launch_bounds__(1024) void quarter_sort_kernel(const uint32_t *__restrict__ cost, const uint32_t *__restrict__ max_cost,
+                                                             int n_quarters, uint32_t *__restrict__ sorted) {
+  __shared__ uint32_t bins[256];
+  __shared__ uint32_t base[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) bins[i] = 0;
+  __syncthreads();
+  const uint32_t mx = *max_cost > 0 ? *max_cost : 1;
+  for (int t = threadIdx.x; t < n_quarters; t += blockDim.x)
+    atomicAdd(&bins[255u - (uint32_t)(((unsigned long long)cost[t] * 255ull) / mx)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 256; i++) base[i] = run, run += bins[i];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < n_quarters; t += blockDim.x)
+    sorted[atomicAdd(&base[255u - (uint32_t)(((unsigned long long)cost[t] * 255ull) / mx)], 1u)] = (uint32_t)t;
+}
+// ... and every 64 consecutive work items of the queue -- what the lanes of a wave pick up together -- are dealt one
+// quarter from each quartile of that order (a snake: b, 2n - 1 - b, 2n + b, 4n - 1 - b): no wave starts on 64 rays of a
+// dense tile (150-260 k cycles per query of a full wave against 40 k for the frame's typical mix; such waves WERE the
+// frame's last per cent), every wave's first 64 pixels cost about the same, and the dearest quarters still go first.
+__global__ __launch_bounds__(256) void snake_map_kernel(const uint32_t *__restrict__ sorted, int n_tiles,
+                                                         uint32_t *__restrict__ qmap) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_tiles) return;
+  const int n = n_tiles;
+  qmap[4 * b + 0] = sorted[b];
+  qmap[4 * b + 1] = sorted[2 * n - 1 - b];
+  qmap[4 * b + 2] = sorted[2 * n + b];
+  qmap[4 * b + 3] = sorted[4 * n - 1 - b];
+}
+hipError_t launch_quarter_order(const uint32_t *d_order, const uint32_t *d_work, const uint32_t *d_rays, int n_tiles,
+                                uint32_t *d_qcost, uint32_t *d_qsorted, uint32_t *d_qmax, uint32_t *d_qmap, hipStream_t stream) {
+  if (!d_work) {
+    hipLaunchKernelGGL(expand_order_kernel, dim3((n_tiles * 4 + 255) / 256), dim3(256), 0, stream, d_order, n_tiles, d_qmap);
+    return hipGetLastError();
+  }
+  hipError_t e = hipMemsetAsync(d_qmax, 0, sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(quarter_cost_kernel, dim3((n_tiles * 4 + 255) / 256), dim3(256), 0, stream, d_work, d_rays, n_tiles * 4,
+                     d_qcost, d_qmax);
+  hipLaunchKernelGGL(quarter_sort_kernel, dim3(1), dim3(1024), 0, stream, d_qcost, d_qmax, n_tiles * 4, d_qsorted);
+  hipLaunchKernelGGL(snake_map_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, d_qsorted, n_tiles, d_qmap);
+  return hipGetLastError();
+}
+
 hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
                              const int head_pct[3], hipStream_t stream) {
@@ -490,11 +557,14 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   size_t lds = 0;
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
   lc.tile_order = plan.tile_order;
+  lc.visit_counts = plan.visit_counts;
   lc.sparse_items = plan.sparse_items;
   lc.head_list = plan.head_list;
   lc.probe_marks = plan.probe_marks;
   lc.sparse_stride = tune.sparse_stride;
   lc.exclusive = tune.exclusive;
+  lc.probe_spp = plan.probe_spp;
+  lc.promote = tune.promote;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),

@@ -176,7 +176,7 @@ __device__ __forceinline__ unsigned long long stat_now() { return stat_real(); }
 template <typename T, bool DT>
 __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, const BvhNode *top, float mag, int *wl,
                                             bool need, V3 o, V3 d, V3 inv_d, T bt_to, uint32_t lo_code,
-                                            unsigned long long *overflow
+                                            unsigned long long *overflow, bool count_work
 #ifdef RTMI_STATS
                                             , MeshStats &st
 #endif
@@ -264,6 +264,9 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, co
       const int owner = (int)((unsigned)e >> 26), fcnt = e & 7;
       int first = (e >> 3) & (kMeshMaxFaces - 1);
       int *rr = wl + owner * kMeshRayWords;
+      // (cost probe) one unit of work per lane and step, booked on the ray it is done for: word 7 of the record, the
+      // high half of a binary64 t_to, is free when t is binary32
+      if (!DT && count_work && mine) atomicAdd(rr + 7, 1);
       if (wide) {
         const int j = lane & 3;
         first += j;
@@ -397,6 +400,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, co
       const int owner = (int)((unsigned)e >> 26), idx = e & (kMeshMaxNodes - 1);
       const uint4 *np = reinterpret_cast<const uint4 *>(sc.qnodes + idx);
       const int *rr = wl + owner * kMeshRayWords;
+      if (!DT && count_work && mine) atomicAdd(wl + owner * kMeshRayWords + 7, 1);
       // children that were touched: nodes onto the node end, face blocks onto the face end
 #define RTMI_PUSH_CHILD(H, C)                                                           \
   {                                                                                     \
@@ -497,4 +501,5 @@ struct Hit {
   uint32_t win;   // winner id
   int32_t aux;    // BVH record index of the winner
   float u, v;     // raw barycentrics of the winning triangle
+  int32_t work;   // (cost probe, mesh variants) lane-steps the wave spent on this ray's searches
 };

@@ -23,8 +23,12 @@ struct LaunchCfg {
   int32_t lds_paths;   // leaf-path words staged in LDS (the first lds_paths of SceneDev::leaf_paths)
   int32_t threads;     // lanes per workgroup (== blockDim.x)
   int32_t nrm_off;     // byte offset of the staged TriNrm records (with pairs_off), -1: not staged
+  int32_t probe_spp;   // samples per pixel of the probe whose counts the head classes' thresholds refer to
+  int32_t promote;     // > 0: mesh frames promote pixels to a head class at run time, from this many samples on (render_body: thr16)
   int32_t cand_off;    // byte offset of the per-lane candidate slots of the grouped sphere scan, -1: none
-  const uint32_t *tile_order;  // optional: the queue hands out local tile tile_order[k] as its k-th tile
+  const uint32_t *tile_order;  // optional: the queue's order, per QUARTER tile (16 work items): its k-th 16 items are
+                               // quarter tile_order[k] (items tile_order[k] * 16 ...)
+  uint32_t *visit_counts;      // optional (cost probe, mesh variants): per work item, lane-steps of its rays' searches
   const uint32_t *head_list;     // optional (with sparse_items): the head's items by weight class (SchedPlan::head_list)
   const uint32_t *probe_marks;   // with head_list: bit 31 of an item's word = it is in the head
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
@@ -102,6 +106,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   const bool f32_jitter = w_pow2 && h_pow2 && fr.width <= (1 << 20) && fr.height <= (1 << 20);  // (wave-uniform)
   // per-lane pixel state
   int32_t q32 = 0;  // the lane's work item (items < 2^31: make_frame); widened where it addresses memory
+  uint32_t work_px = 0;  // (cost probe) lane-steps of the mesh searches of this pixel's rays
   uint32_t ray_acc = 0;  // closest-hit queries of this lane's finished pixels, modulo what it has flushed (below)
   uint32_t pij = 0;  // the pixel's row << 16 | column (frames are below 65536 x 65536: make_frame)
   int k = 0;
@@ -141,6 +146,15 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   const bool classes = (F & F_BVH) && lc.head_list != nullptr && sparse_limit != 0ull;
   uint32_t end64 = 0u, end32 = 0u;
   if (classes) end64 = lc.sparse_items[1], end32 = lc.sparse_items[2];
+  // Promotion at run time (round 3).  The 2-spp probe misses about a third of the outlier pixels (a pixel whose
+  // samples go deep with p = 0.4 looks shallow twice with p = 0.36); such a pixel then sits in a full wave -- 50-100 k
+  // cycles per query instead of 26 k -- whose other lanes keep taking new pixels, and the frame waits for it.  After 16
+  // samples a pixel's own ray count says what the probe could not: from then on a pixel whose rays per sample reach a
+  // head class's threshold (the probe's thresholds, per sample) IS of that class, and its wave thins out around it
+  // like around any head pixel (`exclusive`).  Nothing moves between lanes; only which lanes may fetch changes.
+  uint32_t thr64 = 0xffffffffu, thr32 = 0xffffffffu, thr16 = 0xffffffffu;  // rays per lc.probe_spp samples
+  if (classes && lc.exclusive && lc.promote) thr64 = lc.sparse_items[23], thr32 = lc.sparse_items[24], thr16 = lc.sparse_items[25];
+  const bool promote = thr16 != 0xffffffffu;
   int cls = 1;
   bool head_open = classes;  // (wave-uniform) the head queue may still hold items
   auto take_item = [&](int64_t item) -> bool {  // false: ragged-tile padding (or nothing to sample), written as black
@@ -161,6 +175,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     rng.v4 = states[5 * n_items + q];
     k = 0;
     rays = 0;
+    work_px = 0;
     color = splat(0.f);
     has_px = true;
     return true;
@@ -186,6 +201,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       out[q * 3 + 1] = c.y;
       out[q * 3 + 2] = c.z;
       if (ray_counts) ray_counts[q] = rays;
+      if ((F & F_BVH) && lc.visit_counts != nullptr) lc.visit_counts[q] = work_px;
       // the lane's ray total in ONE register: 2^31 at a time goes to the global counter (a constant addend: the
       // compiler's wave-level combining of atomics needs no scan for it), the rest at the end of the kernel
       ray_acc += rays;
@@ -245,7 +261,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               if (__hip_atomic_load(&counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= sparse_limit) done = true;
               break;
             }
-            const int64_t item = (int64_t)lc.tile_order[mq >> 6] * 64 + (int64_t)(mq & 63);
+            const int64_t item = (int64_t)lc.tile_order[mq >> 4] * 16 + (int64_t)(mq & 15);
             if (lc.probe_marks[item] >> 31) continue;  // a head item: not from this queue
             if (take_item(item)) cls = 1;
           }
@@ -266,7 +282,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           break;
         }
         int64_t item = (int64_t)nq;
-        if (lc.tile_order) item = (int64_t)lc.tile_order[nq >> 6] * 64 + (int64_t)(nq & 63);
+        if (lc.tile_order) item = (int64_t)lc.tile_order[nq >> 4] * 16 + (int64_t)(nq & 15);
         if (!take_item(item)) continue;
         heavy = nq < sparse_limit;
       }
@@ -310,6 +326,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         o = origin;
         d = unit3_rn_twice(target - origin);  // RayAt normalises, Ray's constructor normalises again
         k++;
+        if ((F & F_BVH) && promote && cls == 1 && k >= lc.promote) {
+          const unsigned long long have = (unsigned long long)rays * (unsigned)lc.probe_spp, per = (unsigned long long)k;
+          if (have >= thr16 * per) cls = have >= thr64 * per ? 64 : have >= thr32 * per ? 32 : 16;
+        }
         depth = 0;
         active = true;
       }
@@ -331,7 +351,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     const bool all_lanes_in = (F & F_BVH) || ((F & F_TRIS) && ll != nullptr && sc.n_pairs >= kCullMinPairs) ||
                               ((F & F_SGROUP) && cands != nullptr);  // wave-uniform
     if (all_lanes_in)  // every lane goes in, with or without a ray of its own: see closest_hit
-      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, cands, wl, counters + 2, o, d, active
+      h = closest_hit<F>(sc, s_nodes, lc.lds_nodes, s_paths, lc.lds_paths, s_pairs, ll, cands, wl, counters + 2, o, d, active,
+                         (F & F_BVH) && lc.visit_counts != nullptr
 #ifdef RTMI_STATS
                          , st
 #endif
@@ -343,7 +364,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     // padded bound or distance slack that let an acceptable primitive slip (closest_hit.h, scene.hip) shows as a
     // disagreement.  counters[33] += rays re-done, counters[34] += disagreements (rtmi_debug_counters).
     if (all_lanes_in && !(F & F_BVH) && (check_tick++ & 255u) == 0u) {
-      const Hit h2 = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, nullptr, nullptr, nullptr, nullptr, nullptr, o, d, active);
+      const Hit h2 = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, nullptr, nullptr, nullptr, nullptr, nullptr, o, d, active, false);
       const bool differs = active && (h2.ok != h.ok || (h.ok && (__float_as_uint(h2.t) != __float_as_uint(h.t) || h2.win != h.win)));
       const unsigned long long na = __builtin_amdgcn_ballot_w64(active), nd = __builtin_amdgcn_ballot_w64(differs);
       if ((threadIdx.x & 63u) == 0u) {
@@ -354,12 +375,13 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 #endif
     if (active) {
       if (!all_lanes_in)
-        h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, nullptr, o, d, true
+        h = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, s_pairs, nullptr, nullptr, nullptr, nullptr, o, d, true, false
 #ifdef RTMI_STATS
                            , st
 #endif
         );
       rays++;
+      if ((F & F_BVH) && lc.visit_counts != nullptr) work_px += (uint32_t)h.work;
 
       V3 result = splat(0.f);
       bool ended = true;

@@ -266,7 +266,9 @@ def test_render_opts_validation():
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(ok), dummy, dummy, None, None) == -1
     assert b"not committed" in L.rtmi_last_error()  # the options passed; the scene is what is missing
     # the call's counters + states copy + probe counts + tile costs and order + 32 words + the head list (16,384 entries)
-    assert L.rtmi_render_scratch_bytes(C.byref(fr)) == 40 * 8 + 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 128 + 16384 * 4
+    # + the probe's work counts + per quarter tile: cost, sorted list, order (4 each per tile) + 4 words
+    assert L.rtmi_render_scratch_bytes(C.byref(fr)) == 40 * 8 + 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 128 + 16384 * 4 + \
+        64 * 4 + 1 * 4 * 12 + 16
 
 
 def test_no_cpu_fallback():
