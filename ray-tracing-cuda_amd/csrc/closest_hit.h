@@ -39,10 +39,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
   const bool det_safe = sc.det_safe != 0;  // (a kernel argument: the branch on it waits for no vector result)
   // the ray as the culled list scan wants it: 1/d (the hardware reciprocal will do: the test is conservative by
   // a margin of 1e-5, not 1e-7), and -(o +- delta)/d per axis, delta = the distance slack of the mesh search
-  V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
   // the culled list scan is on when the wave has its task region (ll) and the scene has pair records; the pairs'
   // corners come from LDS when the list was short enough to be staged (s_pairs), else from global memory
   const bool cull_list = (F & F_TRIS) && ll != nullptr && sc.n_pairs >= kCullMinPairs;  // (wave-uniform)
+  V3 cull_inv = splat(0.f), cull_klo = splat(0.f), cull_khi = splat(0.f);
   if ((F & F_TRIS) && cull_list) {
     const float ix = __builtin_amdgcn_rcpf(d.x), iy = __builtin_amdgcn_rcpf(d.y), iz = __builtin_amdgcn_rcpf(d.z);
     cull_inv = mk(fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : ix, fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : iy,
@@ -581,10 +581,12 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       for (int i = 0; i < run.count; i++) {
         BvhRec br;
         {
-          const i32x8 bw = load_bvh_rec(sc.bvhs, run.first + i);  // wave-uniform: scalar load
+          const i32x16 bw = load_bvh_rec(sc.bvhs, run.first + i);  // wave-uniform: one scalar load, root bounds included
           br.root = bw[0], br.mat = bw[1], br.has_uv = bw[2], br.face_base = bw[3], br.sub_root = bw[4];
           br.mag = __int_as_float(bw[5]);
           br.ref_depth = bw[6], br.path_base = bw[7];
+#pragma unroll
+          for (int c = 0; c < 3; c++) br.root_mn[c] = __int_as_float(bw[8 + c]), br.root_mx[c] = __int_as_float(bw[11 + c]);
         }
         T bt_to = t_to;
         bool bhit = false;
@@ -606,10 +608,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         // root's.  The root's bounds are padded far beyond what that binary32 test can get wrong.  (A mesh whose root is
         // a leaf has no box test at all: every face the triangle test accepts counts, from however far off.)
         if (br.ref_depth > 0) {
-          const f32x8 rb = *(const RT_CONSTANT f32x8 *)(uintptr_t)(sc.nodes + br.root);
           BvhNode rn;
-          rn.mn[0] = rb[0], rn.mn[1] = rb[1], rn.mn[2] = rb[2], rn.mx[0] = rb[3], rn.mx[1] = rb[4], rn.mx[2] = rb[5];
-          const float diag = fmaxf(fmaxf(rb[3] - rb[0], rb[4] - rb[1]), rb[5] - rb[2]);
+          rn.mn[0] = br.root_mn[0], rn.mn[1] = br.root_mn[1], rn.mn[2] = br.root_mn[2];
+          rn.mx[0] = br.root_mx[0], rn.mx[1] = br.root_mx[1], rn.mx[2] = br.root_mx[2];
+          const float diag = fmaxf(fmaxf(rn.mx[0] - rn.mn[0], rn.mx[1] - rn.mn[1]), rn.mx[2] - rn.mn[2]);
           const float pad = 1e-3f * diag + 1e-4f * br.mag + 0x1p-15f * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + br.mag);
           need = need && slab_touch(rn, pad, o, inv_d, T_FROM_F * 0.999f, (float)bt_to * 1.0001f + 1e-6f);
         }

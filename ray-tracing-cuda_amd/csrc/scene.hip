@@ -665,6 +665,8 @@ std::string Scene::flatten() {
             br.mag = fmaxf(br.mag, fmaxf(fabsf(local_nodes[0].mn[k]), fabsf(local_nodes[0].mx[k])));
         br.has_uv = has_uv ? 1 : 0;
         br.face_base = face_base;
+        if (!local_nodes.empty())
+          for (int k = 0; k < 3; k++) br.root_mn[k] = local_nodes[0].mn[k], br.root_mx[k] = local_nodes[0].mx[k];
         if (br.root >= 0) {
           build_top_entries(qnodes, br.sub_root, tops);  // row = index of the record
           bvh_recs.push_back(br);

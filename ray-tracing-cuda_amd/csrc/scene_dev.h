@@ -183,7 +183,10 @@ struct BvhRec {  // one per BVH hitable
   float mag;          // largest |coordinate| of the mesh's bounds (scales the search's distance slack)
   int32_t ref_depth;  // decisions on the longest root-to-leaf path of the reference tree (0: the root is a leaf)
   int32_t path_base;  // first word of this mesh's rows in SceneDev::leaf_paths
+  float root_mn[3], root_mx[3];  // the reference root's bounds (nodes[root]): the record is one s_load_dwordx16, and the
+  int32_t pad[2];                // mesh-bounds pre-test of a query waits for one scalar load instead of two in a row
 };
+static_assert(sizeof(BvhRec) == 64, "BvhRec is read with one s_load_dwordx16");
 
 struct alignas(16) FaceRec {  // 48 B; the unit normal is recomputed for the winner only
   float p0[3];

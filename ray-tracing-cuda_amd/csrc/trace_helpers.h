@@ -262,8 +262,8 @@ typedef int i32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ i32x4 load_run(const Run *base, int idx) {
   return *(const RT_CONSTANT i32x4 *)(uintptr_t)(base + idx);
 }
-__device__ __forceinline__ i32x8 load_bvh_rec(const BvhRec *base, int idx) {
-  return *(const RT_CONSTANT i32x8 *)(uintptr_t)(base + idx);
+__device__ __forceinline__ i32x16 load_bvh_rec(const BvhRec *base, int idx) {
+  return *(const RT_CONSTANT i32x16 *)(uintptr_t)(base + idx);
 }
 
 // bvh.cu:6-30 — "the segment crosses the box surface"; a box that wholly
