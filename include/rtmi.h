@@ -137,13 +137,13 @@ int rtmi_scene_commit(rtmi_scene *s);
 /* Counts of the flattened scene: {entries of the world list (a nested list counts once), spheres,
  * parallelograms (incl. box faces), triangles, bvh faces, bvh nodes, materials, textures}. */
 int rtmi_scene_stats(const rtmi_scene *s, int64_t out[8]);
-/* Mesh faces whose smallest interior angle is below 1.4 degrees.  The mesh search finds every face the reference's
- * binary32 triangle test (utils.cu:49-85) can accept for rays that start within ~1e4 face sizes -- by padded bounds
- * plus a slack proportional to the ray origin's distance -- EXCEPT that for thinner faces the test's false accepts
- * reach further than that slack from far away (error ~ 4e-7 x distance / sin(angle)); what the reference returns
- * there depends on its tree's boxes and on rounding, and this library may differ from it on a few pixels per
- * thousand frames of such views (tools/gpu_fuzz.py, third campaign: 4 of 1,000 worlds of 0.6-degree slivers seen
- * from 60 .. 800 away).  0 means the bit-exactness statement of DESIGN.md holds without that reservation. */
+/* Mesh faces whose smallest interior angle is below 1.8 degrees (sine below 1/32).  The reference's binary32 triangle
+ * test (utils.cu:49-85) accepts rays that pass such a face at a distance of about eps x (distance to the ray's origin)
+ * / sin(angle) -- further than the 2^-16 distance slack every search box gets.  Since round 3 the nodes of the search
+ * tree above a thin face widen their children's boxes by what it asks for (8 eps / sin(angle), as a power of two), so
+ * the count is informational: the search cost of rays that come near those nodes grows with it, exactness does not
+ * depend on it (tests: test_far_views_and_thin_faces, test_needles_and_grazing_views_match_the_oracle;
+ * tools/gpu_check_margins.py meshes re-answers every query by the reference's own tree walk). */
 int64_t rtmi_scene_sliver_faces(const rtmi_scene *s);
 /* Algorithmic bytes one closest-hit query consults; BVH scenes
  * need the measured per-ray node/face visits and report only the fixed part. */

@@ -404,6 +404,9 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   if ((rc = upload(s, s->tops, &d.tops))) return rc;
   if ((rc = upload(s, s->faces, &d.faces))) return rc;
   if ((rc = upload(s, s->face_uv, &d.face_uv))) return rc;
+#ifdef RTMI_CHECK_MARGINS
+  if ((rc = upload(s, s->face_of_orig, &d.face_of_orig))) return rc;
+#endif
   if ((rc = upload(s, s->mat_recs, &d.mats))) return rc;
   if ((rc = upload(s, s->tex_recs, &d.texs))) return rc;
   d.n_runs = (int)s->runs.size() - 4;  // without the padding records

@@ -2,6 +2,64 @@
 // Included by kernels.hip inside namespace rtmi, after mesh_search.h (not a stand-alone header).
 #pragma once
 
+#ifdef RTMI_CHECK_MARGINS
+// ================================================================== diagnostic build: the reference's own walk
+// -DRTMI_CHECK_MARGINS (tools/gpu_check_margins.py): BVH::Hit as the reference performs it (bvh.cuh:123-183, bvh.cu:6-30)
+// -- a depth-first walk of ITS tree by the lane that owns the ray, left subtree first, one running t_to; a child's box
+// is tested when the walk reaches it, with AABB::Hit written out plane by plane (not through aabb_crossing_time, which
+// the product's replay uses); a leaf scans its faces in the reference's order.  Nothing of the search structure, its
+// padded boxes or distance slacks takes part, so a face the search lost shows up as a disagreement.
+__device__ inline bool aabb_hit_reference(const BvhNode &nd, V3 o, V3 d, double t_from, double t_to) {
+  const float oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  for (int i = 0; i < 3; i++) {
+    if (dd[i] == 0.f) continue;  // bvh.cu:24
+    for (int s = 0; s < 2; s++) {
+      const float tf = ((s == 0 ? nd.mn[i] : nd.mx[i]) - oo[i]) / dd[i];  // bvh.cu:25 (binary32, widened)
+      const double t = (double)tf;
+      if (t != t || fabs(t) == (double)INFINITY) continue;  // bvh.cu:8
+      if (!(t_from <= t && t <= t_to)) continue;            // bvh.cu:9
+      const float pt[3] = {oo[0] + (float)t * dd[0], oo[1] + (float)t * dd[1], oo[2] + (float)t * dd[2]};  // bvh.cu:10
+      bool inside = true;
+      for (int a = 0; a < 3; a++)
+        if (a != i && !(nd.mn[a] <= pt[a] && pt[a] <= nd.mx[a])) inside = false;
+      if (inside) return true;
+    }
+  }
+  return false;
+}
+template <typename T>
+__device__ inline bool bvh_reference_walk(const SceneDev &sc, const BvhRec &br, V3 o, V3 d, T &t_to, int &face, float &fu,
+                                          float &fv) {
+  int stk_node[kRefDepthMax + 2], stk_first[kRefDepthMax + 2], stk_n[kRefDepthMax + 2];
+  int sp = 1;
+  stk_node[0] = br.root, stk_first[0] = 0, stk_n[0] = br.n_faces;
+  bool hit = false;
+  while (sp > 0) {
+    sp--;
+    const int node = stk_node[sp], first = stk_first[sp], n = stk_n[sp];
+    const BvhNode nd = sc.nodes[node];
+    // bvh.cuh:138-150: every node but the root is entered iff its box is crossed inside [t_from, t_to] NOW
+    if (node != br.root && !aabb_hit_reference(nd, o, d, 1e-3, (double)t_to)) continue;
+    if (nd.right < 0) {  // leaf (bvh.cuh:125-136): faces in the reference's order, each acceptance lowers t_to
+      for (int i = 0; i < n; i++) {
+        const int fi = sc.face_of_orig[br.face_base + first + i];
+        const FaceRec &f = sc.faces[fi];
+        float t = 0.f, u = 0.f, v = 0.f;
+        if (tri_test<T>(mk(f.p0[0], f.p0[1], f.p0[2]), mk(f.e1[0], f.e1[1], f.e1[2]), mk(f.e2[0], f.e2[1], f.e2[2]), o, d,
+                        t_to, t, u, v))
+          t_to = (T)t, face = fi, fu = u, fv = v, hit = true;
+      }
+    } else if (sp + 2 <= kRefDepthMax + 2) {
+      const int mid = (n - 1) / 2;  // bvh.cuh:118
+      stk_node[sp] = nd.right, stk_first[sp] = first + mid + 1, stk_n[sp] = n - mid - 1;
+      stk_node[sp + 1] = nd.left, stk_first[sp + 1] = first, stk_n[sp + 1] = mid + 1;
+      sp += 2;
+    }
+  }
+  return hit;
+}
+#endif
+
 // ================================================================== closest hit
 // HitableList::Hit (hitable_list.cu:7-25) over the flattened world.  A nested
 // Parallelepiped list is equivalent to its six parallelograms inlined at its
@@ -587,11 +645,25 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           br.ref_depth = bw[6], br.path_base = bw[7];
 #pragma unroll
           for (int c = 0; c < 3; c++) br.root_mn[c] = __int_as_float(bw[8 + c]), br.root_mx[c] = __int_as_float(bw[11 + c]);
+          br.n_faces = bw[14], br.slack_exp = bw[15];
         }
         T bt_to = t_to;
         bool bhit = false;
         int bface = 0;
         float fu = 0.f, fv = 0.f;
+#ifdef RTMI_CHECK_MARGINS
+        if (wl == nullptr) {  // (wave-uniform) the checker's second answer: no search, no replay
+          if (live) bhit = bvh_reference_walk<T>(sc, br, o, d, bt_to, bface, fu, fv);
+          const bool acc = bhit && (!ok || bt_to < t_to);
+          ok = ok || acc;
+          t_to = acc ? bt_to : t_to;
+          win = acc ? make_id(RUN_BVH, bface) : win;
+          aux = acc ? run.first + i : aux;
+          bu = acc ? fu : bu;
+          bv = acc ? fv : bv;
+          continue;
+        }
+#endif
         // replay state: path code of the last replayed leaf and, left-aligned like the code,
         // one bit per level "that node of its path was entered"
         bool have_prev = false;
@@ -612,7 +684,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           rn.mn[0] = br.root_mn[0], rn.mn[1] = br.root_mn[1], rn.mn[2] = br.root_mn[2];
           rn.mx[0] = br.root_mx[0], rn.mx[1] = br.root_mx[1], rn.mx[2] = br.root_mx[2];
           const float diag = fmaxf(fmaxf(rn.mx[0] - rn.mn[0], rn.mx[1] - rn.mn[1]), rn.mx[2] - rn.mn[2]);
-          const float pad = 1e-3f * diag + 1e-4f * br.mag + 0x1p-15f * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + br.mag);
+          const float pad = 1e-3f * diag + 1e-4f * br.mag +
+                            ldexpf(0x1p-15f * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + br.mag), br.slack_exp);
           need = need && slab_touch(rn, pad, o, inv_d, T_FROM_F * 0.999f, (float)bt_to * 1.0001f + 1e-6f);
         }
 #endif

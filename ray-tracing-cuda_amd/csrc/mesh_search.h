@@ -61,11 +61,16 @@ __device__ __forceinline__ void node_frame(uint4 w0, float4 r0, float4 r2, float
   const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(r0.x), fabsf(r0.y)), fabsf(r0.z)) + mag);
   const float oo[3] = {r0.x, r0.y, r0.z}, ii[3] = {r2.x, r2.y, r2.z};
   const float org[3] = {__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z)};
+#ifdef RTMI_NO_SLACK_EXP  // (diagnostic: what the exponent is for -- tools/gpu_check_margins.py finds the needles then)
+  const int sk = 0;
+#else
+  const int sk = (int)w0.w >> 24;  // QNode4::slack_exp: thin faces below this node ask for 2^sk times the slack
+#endif
 #pragma unroll
   for (int a = 0; a < 3; a++) {
     const int ex = (int)(int8_t)((w0.w >> (8 * a)) & 0xffu);
     const float oq = ldexpf(oo[a] - org[a], -ex);
-    const float rho = ldexpf(delta, -ex);
+    const float rho = ldexpf(delta, sk - ex);
     // finite even for a clamped reciprocal on a coarse grid: |q - oq| >= rho > 0 keeps the product
     // away from 0 * inf, and med3 keeps it below infinity
     f.idq[a] = __builtin_amdgcn_fmed3f(ldexpf(ii[a], ex), -1e35f, 1e35f);
@@ -224,7 +229,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, co
                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_d.y), rl)),
                        __int_as_float(__builtin_amdgcn_readlane(__float_as_int(inv_d.z), rl)));
       const float rfar = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(far), rl));
-      const float delta = MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)) + mag);
+      const float delta = ldexpf(MESH_DIST_SLACK * (fmaxf(fmaxf(fabsf(ro.x), fabsf(ro.y)), fabsf(ro.z)) + mag), te.right);
       const bool hit = te.left != -1 && slab_touch(te, delta, ro, ri, lo0, rfar);
       const bool pn = hit && te.left >= 0, pf = hit && te.left < 0;
       const unsigned long long mn_ = __builtin_amdgcn_ballot_w64(pn), mf_ = __builtin_amdgcn_ballot_w64(pf);

@@ -182,7 +182,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   };
 
 #ifdef RTMI_CHECK_MARGINS
-  unsigned check_tick = (blockIdx.x * 7u + (threadIdx.x >> 6)) & 255u;  // (wave-uniform) stagger the waves' samples
+#ifndef RTMI_CHECK_EVERY
+#define RTMI_CHECK_EVERY 256u  // (a build with 1 re-does every query: small worlds, tools/gpu_check_margins.py meshes)
+#endif
+  unsigned check_tick = (blockIdx.x * 7u + (threadIdx.x >> 6)) % RTMI_CHECK_EVERY;  // (wave-uniform) stagger the waves' samples
 #endif
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
             const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
@@ -363,9 +366,16 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     // per-lane culls -- the plain wave-uniform walk of the world list, the plain sphere loop -- and compared: a
     // padded bound or distance slack that let an acceptable primitive slip (closest_hit.h, scene.hip) shows as a
     // disagreement.  counters[33] += rays re-done, counters[34] += disagreements (rtmi_debug_counters).
-    if (all_lanes_in && !(F & F_BVH) && (check_tick++ & 255u) == 0u) {
-      const Hit h2 = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, nullptr, nullptr, nullptr, nullptr, nullptr, o, d, active, false);
-      const bool differs = active && (h2.ok != h.ok || (h.ok && (__float_as_uint(h2.t) != __float_as_uint(h.t) || h2.win != h.win)));
+    // Mesh variants: the second answer walks the reference's own tree (closest_hit.h: bvh_reference_walk), thousands
+    // of triangle tests per ray -- for small frames (tools/gpu_check_margins.py).
+    if (all_lanes_in && (check_tick++ % RTMI_CHECK_EVERY) == 0u) {
+      const Hit h2 = closest_hit<F>(sc, s_nodes, 0, s_paths, 0, nullptr, nullptr, nullptr, nullptr, nullptr, o, d, active, false
+#ifdef RTMI_STATS
+                                    , st
+#endif
+      );
+      const bool differs = active && (h2.ok != h.ok || (h.ok && (__float_as_uint(h2.t) != __float_as_uint(h.t) || h2.win != h.win ||
+                                                                 ((F & F_BVH) && h2.aux != h.aux))));
       const unsigned long long na = __builtin_amdgcn_ballot_w64(active), nd = __builtin_amdgcn_ballot_w64(differs);
       if ((threadIdx.x & 63u) == 0u) {
         atomicAdd(&counters[33], (unsigned long long)__popcll(na));

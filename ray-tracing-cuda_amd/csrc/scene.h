@@ -67,7 +67,7 @@ struct Scene {
   std::vector<SphGroup> sph_groups;
   std::vector<SphMember> sph_members;
   float sph_mag = 0.f;
-  int64_t sliver_faces = 0;  // mesh faces with an interior angle below 1.4 degrees (rtmi_scene_sliver_faces)
+  int64_t sliver_faces = 0;  // mesh faces thinner than 1.8 degrees: their nodes carry a slack exponent (rtmi_scene_sliver_faces)
   float list_mag = 0.f;
   int n_pgrams = 0, n_triangles = 0, n_spheres = 0;
   std::vector<BvhRec> bvh_recs;
@@ -78,6 +78,7 @@ struct Scene {
   int sub_depth = 0;  // deepest search tree (levels of QNode4)
   std::vector<FaceRec> faces;
   std::vector<float> face_uv;
+  std::vector<int32_t> face_of_orig;  // (used by -DRTMI_CHECK_MARGINS builds only) reference face order -> physical
   std::vector<MatRec> mat_recs;
   std::vector<TexRec> tex_recs;
   std::vector<void *> dev_allocs;

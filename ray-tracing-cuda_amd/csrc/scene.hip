@@ -154,7 +154,34 @@ struct FacePts {
   int orig;
   uint32_t code;
   int leaf;  // ordinal of the reference leaf in visiting order
+  int kexp;  // slack exponent of the face (face_slack_exponent): the search boxes above it are widened by 2^kexp
 };
+
+// How far from a face a ray can pass and still be accepted by the binary32 Moller-Trumbore test (utils.cu:49-85):
+// the error of dot(tvec, pvec) / det moves the computed (u, v) by about eps |o - p0| / (|e| sin(theta) cos(phi)), i.e.
+// the accepted region reaches about eps |o - p0| / sin(theta) beyond the face (theta: its smallest angle; measured:
+// at most 2.1 eps D / sin(theta), tools/exp/false_accept_reach.py).  The search boxes are widened at query time by
+// 2^-16 of (|o| + the mesh's largest coordinate) -- enough down to sin(theta) = 1/32 (1.8 degrees); a thinner face asks
+// for 8 eps / sin(theta), rounded up to the next power of two: that exponent.  Every node of the search tree carries
+// the largest exponent of the faces below it (QNode4::slack_exp), so a sliver widens the boxes on ITS root-to-leaf
+// path only.  A face whose edges span less than 1e-7 can never pass the test's |det| >= 1e-7 and asks for nothing.
+static int face_slack_exponent(const V3 p[3]) {
+  const double P[3][3] = {{p[0].x, p[0].y, p[0].z}, {p[1].x, p[1].y, p[1].z}, {p[2].x, p[2].y, p[2].z}};
+  double min_sin = 1.0, cross_len = 0.0;
+  for (int a = 0; a < 3; a++) {
+    const double *A = P[a], *B = P[(a + 1) % 3], *Cc = P[(a + 2) % 3];
+    const double u[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, v[3] = {Cc[0] - A[0], Cc[1] - A[1], Cc[2] - A[2]};
+    const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
+    const double lu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), lv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    cross_len = std::sqrt(cx * cx + cy * cy + cz * cz);  // (twice the area: the same for every corner)
+    // (an obtuse corner has a small sine too, but then one of the other two is acute and smaller)
+    min_sin = std::min(min_sin, lu > 0 && lv > 0 ? cross_len / (lu * lv) : 0.0);
+  }
+  if (!(cross_len >= 0.9e-7)) return 0;   // |det| <= |e1 x e2| for a unit direction: never accepted (NaNs: neither)
+  if (!(min_sin < 1.0 / 32)) return 0;
+  const int k = (int)std::ceil(std::log2(1.0 / (32.0 * std::max(min_sin, 1e-12))));
+  return k < 0 ? 0 : k > kSlackExpMax ? kSlackExpMax : k;
+}
 
 // ---- the search tree (DESIGN.md "Mesh queries"): binned-SAH binary tree over the faces, leaves
 // of <= 4 faces, collapsed to four children per node and quantised into QNode4 records.  Which
@@ -164,6 +191,7 @@ struct BinNode {
   float mn[3], mx[3];  // exact bounds of the faces below
   int left = -1, right = -1;
   int first = 0, n = 0;
+  int kexp = 0;  // largest FacePts::kexp below
 };
 
 static inline float face_centroid(const FacePts &f, int a) {
@@ -193,6 +221,7 @@ static int build_bin(std::vector<BinNode> &bn, std::vector<FacePts> &fp, int fir
       const float c = face_centroid(f, k);
       cmn[k] = fminf(cmn[k], c), cmx[k] = fmaxf(cmx[k], c);
     }
+    nd.kexp = std::max(nd.kexp, f.kexp);
   }
   nd.first = first, nd.n = n;
   const int me = (int)bn.size();
@@ -354,6 +383,7 @@ static int collapse4(std::vector<QNode4> &qn, const std::vector<BinNode> &bn, in
     }
     nd.child[c] = child;
   }
+  nd.slack_exp = (int8_t)bn[root].kexp;  // (its children's boxes are widened by this: the largest need below any of them)
   qn[me] = nd;
   *depth = deepest + 1;
   return me;
@@ -376,6 +406,7 @@ static void build_top_entries(const std::vector<QNode4> &qn, int sub_root, std::
   struct Entry {
     float mn[3], mx[3];
     int ref;
+    int kexp;  // slack exponent of the node the box was a child of
   };
   std::vector<Entry> fr;
   auto expand = [&](int node) {
@@ -390,6 +421,7 @@ static void build_top_entries(const std::vector<QNode4> &qn, int sub_root, std::
         e.mx[a] = nextafterf(nextafterf((float)hi, INFINITY), INFINITY);
       }
       e.ref = nd.child[c];
+      e.kexp = nd.slack_exp;
       fr.push_back(e);
     }
   };
@@ -412,11 +444,12 @@ static void build_top_entries(const std::vector<QNode4> &qn, int sub_root, std::
     if (i < (int)fr.size()) {
       for (int a = 0; a < 3; a++) t.mn[a] = fr[(size_t)i].mn[a], t.mx[a] = fr[(size_t)i].mx[a];
       t.left = fr[(size_t)i].ref;
+      t.right = fr[(size_t)i].kexp;
     } else {
       for (int a = 0; a < 3; a++) t.mn[a] = 1.f, t.mx[a] = -1.f;
       t.left = -1;  // unused slot
+      t.right = 0;
     }
-    t.right = 0;
     tops.push_back(t);
   }
 }
@@ -469,7 +502,7 @@ std::string Scene::flatten() {
   pair_boxes.clear(), pair_pts.clear(), tri_nrm.clear(), list_mag = 0.f;
   sph_groups.clear(), sph_members.clear(), sph_mag = 0.f;
   sliver_faces = 0;
-  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(), tops.clear(),
+  runs.clear(), spheres.clear(), tris.clear(), bvh_recs.clear(), face_of_orig.clear(), nodes.clear(), qnodes.clear(), faces.clear(), leaf_paths.clear(), tops.clear(),
       face_uv.clear(), mat_recs.clear(), tex_recs.clear();
   features = 0;
   n_pgrams = n_triangles = n_spheres = 0;
@@ -574,21 +607,8 @@ std::string Scene::flatten() {
             fp[i].p[j] = mk(hb.faces[(size_t)i * 9 + j * 3], hb.faces[(size_t)i * 9 + j * 3 + 1],
                             hb.faces[(size_t)i * 9 + j * 3 + 2]);
           for (int j = 0; j < 6; j++) fp[i].uv[j] = has_uv ? hb.uvs[(size_t)i * 6 + j] : 0.f;
-          {  // smallest interior angle below the search margins' design limit (DESIGN.md "Mesh queries": ~1.4 degrees)?
-            const double P[3][3] = {{fp[i].p[0].x, fp[i].p[0].y, fp[i].p[0].z}, {fp[i].p[1].x, fp[i].p[1].y, fp[i].p[1].z},
-                                    {fp[i].p[2].x, fp[i].p[2].y, fp[i].p[2].z}};
-            double min_sin = 1.0;
-            for (int a = 0; a < 3; a++) {
-              const double *A = P[a], *B = P[(a + 1) % 3], *Cc = P[(a + 2) % 3];
-              const double u[3] = {B[0] - A[0], B[1] - A[1], B[2] - A[2]}, v[3] = {Cc[0] - A[0], Cc[1] - A[1], Cc[2] - A[2]};
-              const double cx = u[1] * v[2] - u[2] * v[1], cy = u[2] * v[0] - u[0] * v[2], cz = u[0] * v[1] - u[1] * v[0];
-              const double lu = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), lv = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-              const double sn = lu > 0 && lv > 0 ? std::sqrt(cx * cx + cy * cy + cz * cz) / (lu * lv) : 0.0;
-              // (an obtuse corner has a small sine too, but then one of the other two is acute and smaller)
-              min_sin = std::min(min_sin, sn);
-            }
-            if (min_sin < 0.0245) sliver_faces++;  // sin(1.4 degrees)
-          }
+          fp[i].kexp = face_slack_exponent(fp[i].p);
+          if (fp[i].kexp > 0) sliver_faces++;  // thinner than 1.8 degrees: its nodes' boxes are widened for it
         }
         int leaf_max = hb.leaf_max > 0 ? hb.leaf_max : 2048;
         if (hb.n > leaf_max)
@@ -646,6 +666,10 @@ std::string Scene::flatten() {
         }
         if (!face_uv.empty() || has_uv) face_uv.resize((size_t)face_base * 6, 0.f);
         if (has_uv) face_uv.resize((size_t)(face_base + hb.n) * 6, 0.f);
+        face_of_orig.resize((size_t)face_base + hb.n, 0);
+        for (int i = 0; i < hb.n; i++) face_of_orig[(size_t)face_base + fp[i].orig] = face_base + i;
+        br.n_faces = hb.n;
+        br.slack_exp = br.sub_root >= 0 ? local_sub[0].slack_exp : 0;  // (the search tree's root is its first node)
         for (int i = 0; i < hb.n; i++) {  // physical order = search-tree order
           TriRec t = make_tri(fp[i].p[0], fp[i].p[1], fp[i].p[2]);
           FaceRec f{};

@@ -147,12 +147,13 @@ struct BvhNode {  // 32 B
 struct alignas(16) QNode4 {  // 64 B
   float origin[3];
   int8_t exp[3];
-  int8_t pad0;
+  int8_t slack_exp;  // the children's boxes are widened by 2^slack_exp times the distance slack (scene.hip: face_slack_exponent)
   uint8_t qlo[3][4];
   uint8_t qhi[3][4];
   uint32_t pad1[2];
   int32_t child[4];
 };
+constexpr int kSlackExpMax = 24;  // 2^24 x 2^-16 of the ray's distance: every box is touched
 constexpr int kSubDepthMax = 80;   // deepest search tree (levels of QNode4) the wave-wide stack can serve
 constexpr int kMeshFaceSlack = 68;  // face-block entries that can wait on the stack while nodes are popped one at a time
 constexpr int kHitSlots = 4;    // per-ray candidate list: one (code, face, t) entry per leaf holding a hit
@@ -184,7 +185,8 @@ struct BvhRec {  // one per BVH hitable
   int32_t ref_depth;  // decisions on the longest root-to-leaf path of the reference tree (0: the root is a leaf)
   int32_t path_base;  // first word of this mesh's rows in SceneDev::leaf_paths
   float root_mn[3], root_mx[3];  // the reference root's bounds (nodes[root]): the record is one s_load_dwordx16, and the
-  int32_t pad[2];                // mesh-bounds pre-test of a query waits for one scalar load instead of two in a row
+  int32_t n_faces;               // mesh-bounds pre-test of a query waits for one scalar load instead of two in a row
+  int32_t slack_exp;             // largest slack exponent of the mesh's faces (the pre-test's share of it)
 };
 static_assert(sizeof(BvhRec) == 64, "BvhRec is read with one s_load_dwordx16");
 
@@ -228,6 +230,9 @@ struct SceneDev {
   int32_t n_leaf_paths;       // words in leaf_paths
   const FaceRec *faces;
   const float *face_uv;  // 6 floats per face or nullptr
+#ifdef RTMI_CHECK_MARGINS
+  const int32_t *face_of_orig;  // (diagnostic build) per mesh, face_base + reference index -> index into `faces`
+#endif
   const MatRec *mats;
   const TexRec *texs;
   int32_t n_runs, n_mats, n_nodes;

@@ -94,7 +94,7 @@ if len(sys.argv) > 3:
     print("soup seeds %d..%d: %d mismatches, %.1fs" % (first, first + int(sys.argv[3]) - 1, bad, time.time() - t0), flush=True)
 
 # ---- third campaign: small meshes seen from far away (tests/test_gpu_round3.py: far_view_world), the regime of
-# binary32 false accepts outside the leaves' exact boxes; worlds with faces below the margins' 1.4-degree design limit
+# binary32 false accepts outside the leaves' exact boxes; worlds with faces thinner than 1.8 degrees (their nodes widen the search boxes for them: scene.hip face_slack_exponent)
 # (rtmi_scene_sliver_faces) are counted apart
 if len(sys.argv) > 4:
     import test_gpu_round3 as t3
