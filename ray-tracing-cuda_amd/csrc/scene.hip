@@ -31,6 +31,8 @@ static HotTri hot_tri(V3 p0, V3 p1, V3 p2, int mat, int flags) {
   return h;
 }
 
+static int face_slack_exponent(const V3 p[3]);
+
 // The per-pair records of the culled list scan: corners and padded bounds (n = 3 or 4 points).
 static void push_pair(Scene &s, const V3 *p, int n, int flags) {
   PairPts pp{};
@@ -54,6 +56,13 @@ static void push_pair(Scene &s, const V3 *p, int n, int flags) {
   // beyond the exact triangle at short range; the distance-proportional part is added at query time
   const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
   for (int c = 0; c < 3; c++) bx.mn[c] -= pad, bx.mx[c] += pad;
+  // A thin triangle (face_slack_exponent: below 1.8 degrees) is accepted by the binary32 test from further off than the
+  // scan's distance slack covers, by a factor that has no bound in the list's terms: its pair is not culled at all
+  // -- unbounded bounds make it a candidate of every ray (the slab test's products stay +-infinity: the ray's
+  // reciprocals are never zero), and its tests decide as in the full scan.
+  const V3 second[3] = {q[1], q[2], q[3]};
+  if (face_slack_exponent(q) > 0 || (n == 4 && face_slack_exponent(second) > 0))
+    for (int c = 0; c < 3; c++) bx.mn[c] = -INFINITY, bx.mx[c] = INFINITY;
   s.list_mag = fmaxf(s.list_mag, mag);
   s.pair_pts.push_back(pp);
   s.pair_boxes.push_back(bx);

@@ -109,6 +109,24 @@ if "lists" not in sys.argv[1:]:
         return make
 
 
+    def needle_list(seed):
+        fill, h, w, spp, depth = t3.needle_list_world(seed)
+
+        def make(b):
+            fill(b)
+            return h, w, spp, depth
+        return make
+
+
+    def sphere_cloud(seed):
+        fill, h, w, spp, depth = t3.far_sphere_cloud(seed)
+
+        def make(b):
+            fill(b)
+            return h, w, spp, depth
+        return make
+
+
     def needle(seed):
         fill, h, w, spp, depth = t3.needle_world(seed)
 
@@ -124,6 +142,8 @@ if "lists" not in sys.argv[1:]:
     campaign("far_views_known_sliver_cases", [(s, far(s)[0]) for s in (1527, 1674, 1675, 1774)])
     campaign("grazing_views", [(s, graze(s)) for s in range(int(os.environ.get("RTMI_CHECK_GRAZE", "300")))])
     campaign("needles", [(s, needle(s)) for s in range(int(os.environ.get("RTMI_CHECK_NEEDLES", "300")))])
+    campaign("far_sphere_clouds", [(s, sphere_cloud(s)) for s in range(int(os.environ.get("RTMI_CHECK_SPHERES", "300")))])
+    campaign("needle_lists", [(s, needle_list(s)) for s in range(int(os.environ.get("RTMI_CHECK_NEEDLE_LISTS", "300")))])
 print(json.dumps(out, indent=1))
 hard = [k for k, v in out.items() if v["disagreements"]]
 sys.exit(1 if hard else 0)
