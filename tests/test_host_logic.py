@@ -241,6 +241,26 @@ def test_nested_list_bookkeeping():
         b2.sky()  # the world list itself is full at 1024 entries, the nested list having counted once
 
 
+def test_thin_faces_are_counted_by_what_their_nodes_must_cover():
+    """rtmi_scene_sliver_faces = mesh faces whose nodes carry a slack exponent (scene.hip: face_slack_exponent): smallest
+    angle below asin(1/32) = 1.79 degrees, unless the face is too small for the triangle test's |det| >= 1e-7 ever to
+    hold (|e1 x e2| < 1e-7: never accepted, nothing to widen for)."""
+    def count(faces):
+        b = rtmi.SceneBuilder(1)
+        b.camera_pinhole(v3(0, 0, 1), v3(0, 0, 0), v3(0, 1, 0), 1.0, 1.0)
+        b.bvh(np.asarray(faces, dtype=np.float32), b.lambertian(v3(1, 1, 1)), k_min=2)
+        return b.sliver_faces()
+
+    def tri(angle_deg, size):
+        a = np.radians(angle_deg)
+        return [[0, 0, 0], [size, 0, 0], [size * np.cos(a), size * np.sin(a), 0]]
+    assert count([tri(60, 0.1), tri(2.0, 0.1), tri(1.8, 0.1)]) == 0
+    assert count([tri(60, 0.1), tri(1.75, 0.1), tri(0.01, 0.1)]) == 2
+    assert count([tri(178.5, 0.1)]) == 1          # obtuse: the two other corners are the thin ones
+    assert count([tri(0.5, 1e-4)]) == 0            # 1e-8 x sin: below the test's determinant cut-off whatever the ray
+    assert count([tri(0.5, 3e-3)]) == 0 and count([tri(0.5, 5e-3)]) == 1   # |e1 x e2| = 7.9e-8 / 2.2e-7
+
+
 def test_render_opts_validation():
     """rtmi_render_ex checks its per-call options before anything else touches them."""
     import ctypes as C
