@@ -40,6 +40,15 @@ def run(tag, b, h, w, spp, depth):
     out[tag] = {"rays": R.total_rays(), "re_done": redone, "disagreements": bad}
 
 
+SCENES_EVERY = "scenes" in sys.argv[1:]  # (with a -DRTMI_CHECK_EVERY=1 build: every query of the four scene programs' worlds)
+if SCENES_EVERY:
+    big = os.environ.get("RTMI_CHECK_SCALE") == "big"
+    for name, side, spp, depth in ((("cornell_box", 1024, 64, 50), ("spheres", 1024, 16, 8), ("birthday", 1024, 16, 10), ("bunny", 384, 16, 10))
+                                   if big else (("cornell_box", 256, 64, 50), ("spheres", 256, 16, 8), ("birthday", 256, 16, 10), ("bunny", 192, 8, 10))):
+        b = bench.build_scene(rtmi.SceneBuilder(scenes.SCENE_SEEDS[name]), name, 1.0)
+        run("%s_%dx%dx%d_d%d_every_query" % (name, side, side, spp, depth), b, side, side, spp, depth)
+    print(json.dumps(out, indent=1))
+    sys.exit(1 if any(v["disagreements"] for v in out.values()) else 0)
 ONLY_MESHES = "meshes" in sys.argv[1:]  # (with a -DRTMI_CHECK_EVERY=1 build: every query of the small mesh worlds)
 for name, side, spp, depth in (() if ONLY_MESHES else (("cornell_box", 256, 64, 50), ("spheres", 256, 16, 8), ("birthday", 128, 16, 10))):
     b = bench.build_scene(rtmi.SceneBuilder(scenes.SCENE_SEEDS[name]), name, 1.0)
