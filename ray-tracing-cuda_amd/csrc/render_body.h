@@ -82,6 +82,11 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     const float4 c = load_lds<float4>(s_mats + m);
     return mk(c.x, c.y, c.z);
   };
+  // a byte of dynamic LDS by its byte offset.  The kernels declare no static LDS, so the dynamic array starts at LDS
+  // address 0 (group_segment_fixed_size == 0 in the code object: tests/test_host_logic.py) and the offset IS the address.
+  auto lds_byte = [&](uint32_t byte_offset) -> uint32_t {
+    return *(const RT_LDS uint8_t *)(uintptr_t)byte_offset;
+  };
   const bool fast_fold = mats_in_lds && lc.wide_ids != 1 && sc.unsigned_colours;  // see the radiance fold
   if (mats_in_lds) {
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sc.mats);
@@ -552,17 +557,21 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         int i = depth - 1;
         if (!(F & F_TEX) && fast_fold) {
           // common case (byte ids, material table in LDS, no signed colours) without the per-layer
-          // uniform branches: four layers at a time, ids first, then colours, then the products
+          // uniform branches: four layers at a time, ids first, then colours, then the products.
+          // The id bytes are read at a RUNNING byte offset that steps down a row at a time, as an LDS address proper
+          // (lds_byte): `smem[ids_offset(level)]` cost a 32-bit multiply per group of levels and an addition of the
+          // array's link-time base -- zero -- per byte.  The wave folds as long as its deepest finished path is
+          // (17 levels on average in a Cornell box: the deepest of the ten paths that end per iteration).
           const uint32_t step = n_threads;
           if (nibble_ids) {
+            uint32_t at = ids_offset(i >= 0 ? i >> 1 : 0);
             if (i >= 0 && !(i & 1)) {  // an even top level sits alone in the low half of its byte
-              const int m0 = smem[ids_offset(i >> 1)] & 15;
+              const int m0 = lds_byte(at) & 15;
               { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
-              i--;
+              i--, at -= step;
             }
-            for (; i >= 3; i -= 4) {  // i odd: bytes (i >> 1) and (i >> 1) - 1 hold levels i, i - 1 and i - 2, i - 3
-              const uint32_t at = ids_offset(i >> 1);
-              const uint32_t b0 = smem[at], b1 = smem[at - step];
+            for (; i >= 3; i -= 4, at -= 2u * step) {  // i odd: bytes (i >> 1) and (i >> 1) - 1 hold levels i, i - 1 and i - 2, i - 3
+              const uint32_t b0 = lds_byte(at), b1 = lds_byte(at - step);
               const int m0 = b0 >> 4, m1 = b0 & 15, m2 = b1 >> 4, m3 = b1 & 15;
               const V3 a0 = lds_rgb(m0), a1 = lds_rgb(m1);
               const V3 a2 = lds_rgb(m2), a3 = lds_rgb(m3);
@@ -571,26 +580,27 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
               result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
               result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
             }
-            for (; i >= 1; i -= 2) {
-              const uint32_t b0 = smem[ids_offset(i >> 1)];
+            for (; i >= 1; i -= 2, at -= step) {
+              const uint32_t b0 = lds_byte(at);
               const int m0 = b0 >> 4, m1 = b0 & 15;
               { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
               { const V3 a_ = lds_rgb(m1); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
             }
-          }
-          for (; i >= 3; i -= 4) {
-            const uint32_t at = ids_offset(i);
-            const int m0 = smem[at], m1 = smem[at - step], m2 = smem[at - 2u * step], m3 = smem[at - 3u * step];
-            const V3 a0 = lds_rgb(m0), a1 = lds_rgb(m1);
-            const V3 a2 = lds_rgb(m2), a3 = lds_rgb(m3);
-            result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
-            result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
-            result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
-            result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
-          }
-          for (; i >= 0; i--) {
-            const int m0 = smem[ids_offset(i)];
-            { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
+          } else {
+            uint32_t at = ids_offset(i >= 0 ? i : 0);
+            for (; i >= 3; i -= 4, at -= 4u * step) {
+              const int m0 = lds_byte(at), m1 = lds_byte(at - step), m2 = lds_byte(at - 2u * step), m3 = lds_byte(at - 3u * step);
+              const V3 a0 = lds_rgb(m0), a1 = lds_rgb(m1);
+              const V3 a2 = lds_rgb(m2), a3 = lds_rgb(m3);
+              result = mk(a0.x * result.x, a0.y * result.y, a0.z * result.z);
+              result = mk(a1.x * result.x, a1.y * result.y, a1.z * result.z);
+              result = mk(a2.x * result.x, a2.y * result.y, a2.z * result.z);
+              result = mk(a3.x * result.x, a3.y * result.y, a3.z * result.z);
+            }
+            for (; i >= 0; i--, at -= step) {
+              const int m0 = lds_byte(at);
+              { const V3 a_ = lds_rgb(m0); result = mk(a_.x * result.x, a_.y * result.y, a_.z * result.z); }
+            }
           }
         }
         for (; i >= 0; i--) {

@@ -261,6 +261,30 @@ def test_thin_faces_are_counted_by_what_their_nodes_must_cover():
     assert count([tri(0.5, 3e-3)]) == 0 and count([tri(0.5, 5e-3)]) == 1   # |e1 x e2| = 7.9e-8 / 2.2e-7
 
 
+def test_trace_kernels_declare_no_static_lds():
+    """render_body.h reads the id stack at LDS addresses formed from byte offsets of the DYNAMIC LDS array (lds_byte):
+    that is only right while the array starts at LDS address 0, i.e. while no trace kernel declares static LDS
+    (group_segment_fixed_size == 0 in the code object's metadata)."""
+    import subprocess
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(llvm + "/llvm-readelf"):
+        pytest.skip("no llvm-readelf")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fatbin"), os.path.join(tmp, "co.o")
+        subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", rtmi.LIB_PATH, fat])
+        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
+        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co], text=True)
+    seen = 0
+    for blk in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "render_kernel" in name or "probe_kernel" in name:
+            seen += 1
+            assert re.search(r"\.group_segment_fixed_size:\s+0\b", blk), name
+    assert seen >= 18
+
+
 def test_render_opts_validation():
     """rtmi_render_ex checks its per-call options before anything else touches them."""
     import ctypes as C
