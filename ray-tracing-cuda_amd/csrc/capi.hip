@@ -60,6 +60,9 @@ static RenderTuning default_tuning() {
     if (g_tune.promote < 0) g_tune.promote = 0;
     g_tune.probe_spp = env_int("RTMI_PROBE_SPP", 0);
     if (g_tune.probe_spp < 0 || g_tune.probe_spp > 64) g_tune.probe_spp = 0;
+    g_tune.plan = env_int("RTMI_PLAN", 1) ? 1 : 0;  // list frames: planned chains instead of the queue
+    g_tune.prio_every = env_int("RTMI_PRIO", 16);  // wave priorities: update interval in iterations (0: off)
+    if (g_tune.prio_every < 0 || (g_tune.prio_every & (g_tune.prio_every - 1)) != 0) g_tune.prio_every = 16;
   });
   std::lock_guard<std::mutex> lk(g_tune_mu);
   return g_tune;
@@ -434,7 +437,8 @@ int rtmi_scene_commit(rtmi_scene *sp) {
   d.cam = s->cam;
   s->dev = d;
   void *c = nullptr;
-  HIP_TRY(hipMalloc(&c, RTMI_COUNTER_WORDS * sizeof(unsigned long long)));
+  // (behind the counters: the two kernel-argument blocks of a render without caller-owned scratch -- probe pass, real pass)
+  HIP_TRY(hipMalloc(&c, RTMI_COUNTER_WORDS * sizeof(unsigned long long) + 2 * render_params_bytes()));
   s->dev_allocs.push_back(c);
   HIP_TRY(hipMemset(c, 0, RTMI_COUNTER_WORDS * sizeof(unsigned long long)));
   s->d_counters = reinterpret_cast<unsigned long long *>(c);
@@ -560,10 +564,17 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 // [ quarters sorted ][ quarter order ][ 4 words ].  The counters come first so that
 // rtmi_render_status can find them from the scratch pointer alone.
 static constexpr size_t kCounterBytes = RTMI_COUNTER_WORDS * sizeof(unsigned long long);
+static size_t scratch_body_bytes(const FrameDev &d);
 static size_t scratch_bytes_of(const FrameDev &d) {
   const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-  return kCounterBytes + n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4 +
-         n * 4 + nt * 4 * 12 + 16;  // + the probe's work counts, the quarter-tile costs, their sorted list, the order
+  return scratch_body_bytes(d) + kPrioTabBytes + 2 * render_params_bytes();
+}
+static size_t scratch_body_bytes(const FrameDev &d) {
+  const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
+  return (kCounterBytes + n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4 +
+         n * 4 + nt * 4 * 14 + 16 + 255) & ~(size_t)255;  // + the probe's work counts, the quarter-tile costs, their sorted
+                                                     // list, the order, the chain plan; then the wave-priority table and
+                                                     // the two kernel-argument blocks (scratch_bytes_of)
 }
 size_t rtmi_render_scratch_bytes(const rtmi_frame *f) {
   FrameDev d;
@@ -688,6 +699,9 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   // shards on one device) then share nothing but the read-only scene.  Without one the scene's own (a cache, not
   // scene state) is used, which ties renders of this scene to one at a time.
   unsigned long long *counters = user_scratch ? reinterpret_cast<unsigned long long *>(user_scratch) : s->d_counters;
+  // the kernels' argument blocks (kernels.hip: RenderParams): probe pass, real pass
+  char *params = user_scratch ? reinterpret_cast<char *>(user_scratch) + scratch_body_bytes(d) + kPrioTabBytes
+                              : reinterpret_cast<char *>(s->d_counters) + kCounterBytes;
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
   SchedPlan plan;
@@ -697,20 +711,27 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   const int64_t resident = (int64_t)blocks * threads;
   const int probe_spp = tune.probe_spp > 0 ? tune.probe_spp : 2;
   const bool many_tiles = (int64_t)d.local_tiles * 64 > resident;
-  if (tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles)) {
-    const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
-    void *scratch = user_scratch;
-    if (!scratch) {
-      Scene *ms = const_cast<Scene *>(s);
-      std::lock_guard<std::mutex> lk(g_mu);  // (re)allocation only
-      if (ms->sched_bytes < need) {
-        if (ms->d_sched) (void)hipFree(ms->d_sched);
-        ms->d_sched = nullptr, ms->sched_bytes = 0;
-        HIP_TRY(hipMalloc(&ms->d_sched, need));
-        ms->sched_bytes = need;
-      }
-      scratch = ms->d_sched;
+  const bool scheduled = tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles);
+  // wave priorities (render_body.h: wave_priority_update) pay for themselves when a wave lives for many updates
+  const bool prio = tune.prio_every > 0 && d.spp >= 64;
+  void *scratch = user_scratch;
+  if (!scratch && (scheduled || prio)) {
+    Scene *ms = const_cast<Scene *>(s);
+    std::lock_guard<std::mutex> lk(g_mu);  // (re)allocation only
+    if (ms->sched_bytes < need) {
+      if (ms->d_sched) (void)hipFree(ms->d_sched);
+      ms->d_sched = nullptr, ms->sched_bytes = 0;
+      HIP_TRY(hipMalloc(&ms->d_sched, need));
+      ms->sched_bytes = need;
     }
+    scratch = ms->d_sched;
+  }
+  if (prio) {
+    plan.prio_tab = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(scratch) + scratch_body_bytes(d));
+    HIP_TRY(hipMemsetAsync(plan.prio_tab, 0, kPrioTabBytes, st));
+  }
+  if (scheduled) {
+    const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
     uint32_t *p_states = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(scratch) + kCounterBytes);
     uint32_t *p_rays = p_states + n * RTMI_STATE_WORDS;
     uint32_t *p_cost = p_rays + n;
@@ -718,6 +739,8 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_meta = p_order + nt;  // 16 + 16 words (launch_tile_order); 450 * nt words in: 8-byte aligned
     uint32_t *p_work = p_meta + 32 + kHeadCap;
     uint32_t *p_qcost = p_work + n, *p_qsorted = p_qcost + 4 * nt, *p_qmap = p_qsorted + 4 * nt, *p_qmax = p_qmap + 4 * nt;
+    uint32_t *p_fut = p_qmax + 4;
+    int32_t *p_next = reinterpret_cast<int32_t *>(p_fut + nt);
     // mesh frames (binary32 t): the probe also books the lane-steps of its mesh searches on the pixels they serve
     static const bool cost_probe = env_int("RTMI_COST_PROBE", 1) != 0;
     const bool by_cost = cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
@@ -732,7 +755,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
       probe_plan.visit_counts = p_work;
     }
     HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, counters, probe_plan, true, blocks,
-                          threads, tune, st));
+                          threads, tune, params, st));
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
     // the head of a mesh frame's queue: pixels in weight classes (the default), or -- when the call names a
     // sparse stride, or RTMI_HEAD_CLASSES=0 -- the outlier tiles at one pixel per that many lanes
@@ -749,10 +772,18 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     plan.head_list = p_head;
     plan.probe_marks = p_head ? p_rays : nullptr;
     plan.probe_spp = probe_spp;
+    plan.tile_cost = p_cost;
+    // list frames: planned chains instead of the queue (kernels.h: launch_chain_plan)
+    if (tune.plan && !(variant & F_BVH)) {
+      const int grid_waves = blocks * (threads / 64);
+      HIP_TRY(launch_chain_plan(p_order, p_cost, d.local_tiles, grid_waves, d.spp, probe_spp, p_next, p_fut, st));
+      plan.chain_next = p_next, plan.chain_fut = p_fut, plan.chain_first = p_order;
+      plan.n_chains = grid_waves < d.local_tiles ? grid_waves : d.local_tiles;
+    }
   }
   HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
   HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts, counters,
-                        plan, false, blocks, threads, tune, st));
+                        plan, false, blocks, threads, tune, params + render_params_bytes(), st));
   return RTMI_OK;
 }
 

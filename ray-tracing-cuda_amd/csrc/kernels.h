@@ -33,7 +33,10 @@ struct RenderTuning {
   int head_pct[3];    // mesh frames: per cent of the frame's largest probe count from which a pixel gets a wave to itself,
                       // shares one with another, gets one lane in 16 (80 / 55 / 30)
   int probe_spp;      // samples per pixel of the scheduler's cost probe; 0: chosen per frame (capi.hip)
-  int promote;        // 1: mesh frames promote pixels to a head class at run time
+  int promote;        // samples after which a mesh frame's pixel may be promoted to a head class by its own ray count; 0: never
+  int plan;           // 1: list frames with a probe behind them are rendered as planned chains (launch_chain_plan), not from the queue
+  int prio_every;     // > 0: the waves of a SIMD are served longest-remaining-chain-first, each looking at its priority every
+                      // this many iterations (a power of two); 0: the hardware's oldest-first order
 };
 // What the scheduler's probe pass leaves for the real pass (device pointers, all optional).
 struct SchedPlan {
@@ -44,10 +47,21 @@ struct SchedPlan {
   const uint32_t *head_list = nullptr;     // optional: the head's work items, heaviest pixels first (kHeadCap words)
   const uint32_t *probe_marks = nullptr;   // with head_list: per work item, bit 31 set = listed in the head
   int probe_spp = 2;                       // samples per pixel of the probe behind these (thresholds: sparse_items[23..25])
+  uint32_t *prio_tab = nullptr;            // optional: the wave-priority table (render_body.h: kPrioRows x 16 words, zeroed)
+  const uint32_t *tile_cost = nullptr;     // optional: the probe's ray count per tile (launch_tile_order's d_cost)
+  // planned chains (launch_chain_plan): all three or none
+  const int32_t *chain_next = nullptr;
+  const uint32_t *chain_fut = nullptr;
+  const uint32_t *chain_first = nullptr;   // (= the longest-first tile order)
+  int n_chains = 0;
 };
+constexpr size_t kPrioTabBytes = (size_t)(1 << 14) * 16 * sizeof(uint32_t);
+// d_params: render_params_bytes() of device memory that stays untouched until the launch has finished (the kernel's
+// argument block, written in stream order just before it).
+size_t render_params_bytes();
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan, bool probe,
-                         int blocks, int threads, const RenderTuning &tune, hipStream_t stream);
+                         int blocks, int threads, const RenderTuning &tune, void *d_params, hipStream_t stream);
 // Tiles sorted by descending cost (sum of 64 ray counts each); d_cost/d_order hold n_tiles words,
 // d_meta 16: [0] the largest tile cost, [1] the sparse item count.
 // sparse_cap: work items the grid holds at one pixel per tune.sparse_stride lanes (a multiple of 64).
@@ -64,6 +78,13 @@ hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_co
 // 64-item blocks in a snake (kernels.hip).  d_qcost / d_qsorted: 4 * n_tiles words of scratch each, d_qmax one word.
 hipError_t launch_quarter_order(const uint32_t *d_order, const uint32_t *d_work, const uint32_t *d_rays, int n_tiles,
                                 uint32_t *d_qcost, uint32_t *d_qsorted, uint32_t *d_qmax, uint32_t *d_qmap, hipStream_t stream);
+
+// Planned chains for list frames: the tiles in longest-first order (d_order) are dealt to the grid's waves in a snake
+// -- wave w of W gets ranks w, 2W - 1 - w, 2W + w, ... -- so that every wave's chain costs about the same (ranks beyond
+// the first round pair the lightest tiles with the lightest first tiles).  d_next[tile] = the tile after it in its
+// chain (-1: none), d_fut[tile] = estimated queries per lane of the tiles after it: d_cost x spp / (64 probe_spp).
+hipError_t launch_chain_plan(const uint32_t *d_order, const uint32_t *d_cost, int n_tiles, int grid_waves, int spp,
+                             int probe_spp, int32_t *d_next, uint32_t *d_fut, hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);

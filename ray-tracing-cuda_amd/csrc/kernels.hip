@@ -135,19 +135,36 @@ __global__ __launch_bounds__(256) void rng_init_kernel(uint64_t seed, FrameDev f
 // Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
 // workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
 #define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)
+// Everything the trace kernel is told lives in ONE block of device memory (written by params_write_kernel, stream-ordered,
+// just before the launch) and the kernel's only argument is its address.  By-value kernel arguments are all loaded in
+// the kernel's first block and stay live from there: with ~150 dwords of them the list kernel parked 76-114 scalars in
+// spill lanes (v_writelane / v_readlane at every use), the mesh kernel 285.  Read through the constant address space
+// the fields arrive by scalar loads where they are used -- the hot loop's stay in SGPRs, the rest never occupy one.
+struct RenderParams {
+  SceneDev sc;
+  FrameDev fr;
+  LaunchCfg lc;
+  uint32_t *states;
+  float *out;
+  uint32_t *ray_counts;
+  unsigned long long *counters;
+};
+__global__ void params_write_kernel(RenderParams p, RenderParams *dst) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = p;
+}
+size_t render_params_bytes() { return (sizeof(RenderParams) + 255) & ~(size_t)255; }
+
 template <uint32_t F>
-__global__ __launch_bounds__(RTMI_MAX_THREADS(F), RTMI_MIN_WAVES(F)) void render_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
-                                                      uint32_t *__restrict__ states, float *__restrict__ out,
-                                                      uint32_t *__restrict__ ray_counts,
-                                                      unsigned long long *__restrict__ counters) {
-  render_body<F>(sc, fr, lc, states, out, ray_counts, counters);
+__global__ __launch_bounds__(RTMI_MAX_THREADS(F), RTMI_MIN_WAVES(F)) void render_kernel(const RenderParams *p) {
+  // (global -> constant address space -> generic: the compiler's address-space inference turns every access through
+  // kp back into a constant-address-space load, i.e. a scalar load that nothing in the kernel can clobber)
+  const RenderParams *kp = (const RenderParams *)(const RT_CONSTANT RenderParams *)(uintptr_t)p;
+  render_body<F>(kp->sc, kp->fr, kp->lc, kp->states, kp->out, kp->ray_counts, kp->counters);
 }
 template <uint32_t F>
-__global__ __launch_bounds__(RTMI_MAX_THREADS(F), RTMI_MIN_WAVES(F)) void probe_kernel(SceneDev sc, FrameDev fr, LaunchCfg lc,
-                                                     uint32_t *__restrict__ states, float *__restrict__ out,
-                                                     uint32_t *__restrict__ ray_counts,
-                                                     unsigned long long *__restrict__ counters) {
-  render_body<F>(sc, fr, lc, states, out, ray_counts, counters);
+__global__ __launch_bounds__(RTMI_MAX_THREADS(F), RTMI_MIN_WAVES(F)) void probe_kernel(const RenderParams *p) {
+  const RenderParams *kp = (const RenderParams *)(const RT_CONSTANT RenderParams *)(uintptr_t)p;
+  render_body<F>(kp->sc, kp->fr, kp->lc, kp->states, kp->out, kp->ray_counts, kp->counters);
 }
 
 // ------------------------------------------------------------------ untile / post
@@ -381,6 +398,35 @@ hipError_t launch_quarter_order(const uint32_t *d_order, const uint32_t *d_work,
   return hipGetLastError();
 }
 
+// One thread per wave of the render grid: its chain (ranks k W + (k odd ? W - 1 - w : w) of the longest-first
+// order), walked backwards so that every tile learns what follows it.
+__global__ __launch_bounds__(256) void chain_link_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ cost,
+                                                          int n_tiles, int n_waves, float scale, int32_t *__restrict__ next,
+                                                          uint32_t *__restrict__ fut) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_waves || w >= n_tiles) return;
+  auto rank = [&](int k) -> int64_t { return (int64_t)k * n_waves + ((k & 1) ? n_waves - 1 - w : w); };
+  int steps = 0;
+  while (rank(steps) < n_tiles) steps++;
+  float acc = 0.f;
+  int32_t after = -1;
+  for (int k = steps - 1; k >= 0; k--) {
+    const uint32_t t = order[rank(k)];
+    next[t] = after;
+    fut[t] = (uint32_t)fminf(acc, 4.0e9f);
+    acc += (float)cost[t] * scale;
+    after = (int32_t)t;
+  }
+}
+hipError_t launch_chain_plan(const uint32_t *d_order, const uint32_t *d_cost, int n_tiles, int grid_waves, int spp,
+                             int probe_spp, int32_t *d_next, uint32_t *d_fut, hipStream_t stream) {
+  const int n = grid_waves < n_tiles ? grid_waves : n_tiles;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(chain_link_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_order, d_cost, n_tiles, grid_waves,
+                     (float)spp / (64.f * (float)probe_spp), d_next, d_fut);
+  return hipGetLastError();
+}
+
 hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_cost, uint32_t *d_meta,
                              uint32_t *d_order, uint32_t *d_head, uint32_t sparse_cap, int grid_waves, int outlier_x10,
                              const int head_pct[3], hipStream_t stream) {
@@ -553,7 +599,8 @@ static LaunchCfg make_cfg(uint32_t variant, const SceneDev &sc, const FrameDev &
 template <uint32_t F>
 static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                                   uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan,
-                                  bool probe, int blocks, int threads, const RenderTuning &tune, hipStream_t stream) {
+                                  bool probe, int blocks, int threads, const RenderTuning &tune, void *d_params,
+                                  hipStream_t stream) {
   size_t lds = 0;
   LaunchCfg lc = make_cfg(F, sc, fr, threads, &lds);
   lc.tile_order = plan.tile_order;
@@ -565,18 +612,27 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.exclusive = tune.exclusive;
   lc.probe_spp = plan.probe_spp;
   lc.promote = tune.promote;
+  lc.prio_tab = probe ? nullptr : plan.prio_tab;
+  lc.tile_cost = plan.tile_cost;
+  lc.rate_scale = 1.f / (64.f * (float)(plan.probe_spp > 0 ? plan.probe_spp : 1));
+  lc.chain_next = (F & F_BVH) ? nullptr : plan.chain_next;
+  lc.chain_fut = plan.chain_fut, lc.chain_first = plan.chain_first, lc.n_chains = plan.n_chains;
+  lc.prio_every = tune.prio_every > 0 ? tune.prio_every : 16;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
+  RenderParams rp;
+  rp.sc = sc, rp.fr = fr, rp.lc = lc;
+  rp.states = d_states, rp.out = d_out, rp.ray_counts = d_ray_counts, rp.counters = d_counters;
+  RenderParams *dp = reinterpret_cast<RenderParams *>(d_params);
+  hipLaunchKernelGGL(params_write_kernel, dim3(1), dim3(64), 0, stream, rp, dp);
   if (probe) {
-    hipLaunchKernelGGL(probe_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
-                       d_ray_counts, d_counters);
+    hipLaunchKernelGGL(probe_kernel<F>, dim3(blocks), dim3(threads), lds, stream, (const RenderParams *)dp);
   } else {
-    hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), lds, stream, sc, fr, lc, d_states, d_out,
-                       d_ray_counts, d_counters);
+    hipLaunchKernelGGL(render_kernel<F>, dim3(blocks), dim3(threads), lds, stream, (const RenderParams *)dp);
   }
   return hipGetLastError();
 }
@@ -625,11 +681,11 @@ int render_occupancy(uint32_t variant, const SceneDev &sc, const FrameDev &fr, i
 
 hipError_t launch_render(uint32_t variant, const SceneDev &sc, const FrameDev &fr, uint32_t *d_states, float *d_out,
                          uint32_t *d_ray_counts, unsigned long long *d_counters, const SchedPlan &plan, bool probe,
-                         int blocks, int threads, const RenderTuning &tune, hipStream_t stream) {
+                         int blocks, int threads, const RenderTuning &tune, void *d_params, hipStream_t stream) {
 #define X(V) \
   if (variant == (uint32_t)(V)) \
     return launch_render_t<(V)>(sc, fr, d_states, d_out, d_ray_counts, d_counters, plan, probe, blocks, threads, tune, \
-                                stream);
+                                d_params, stream);
   RTMI_FOR_EACH_VARIANT(X)
 #undef X
   return hipErrorInvalidValue;

@@ -33,7 +33,51 @@ struct LaunchCfg {
   const uint32_t *probe_marks;   // with head_list: bit 31 of an item's word = it is in the head
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
+  int32_t prio_every;            // with prio_tab: a wave looks at its priority every this many iterations (power of two)
+  uint32_t *prio_tab;            // optional: kPrioRows x 16 words, zeroed per launch -- per SIMD (row: XCC | SE | SH | CU | SIMD
+                                 // of HW_ID) and wave slot (column: HW_ID.WAVE_ID), the queries the wave still has to do
+  // Planned chains (list variants; kernels.hip: chain_link_kernel): instead of the queue every wave walks a chain of
+  // tiles fixed before the launch, lane l rendering pixel l of each.
+  const int32_t *chain_next;     // optional: per local tile, the tile that follows it in its wave's chain, -1: the last
+  const uint32_t *chain_fut;     // with chain_next: per tile, estimated queries per lane of the tiles after it in its chain
+  const uint32_t *chain_first;   // with chain_next: wave w (dispatch order) starts on tile chain_first[w] (w < n_chains)
+  int32_t n_chains;              // waves that have a chain (min(waves of the grid, local tiles))
+  const uint32_t *tile_cost;     // optional: the probe's ray count per tile (64 pixels x probe_spp samples): a pixel's
+  float rate_scale;              // rays per sample are first taken as tile_cost x rate_scale = 1 / (64 probe_spp)
 };
+constexpr int kPrioRows = 1 << 14;
+
+// Longest-remaining-chain-first between the waves of a SIMD (DESIGN "Wave priorities").  A SIMD's issue arbiter serves
+// the highest s_setprio level first and the OLDEST wave within a level: left alone, the first-dispatched wave of a
+// SIMD runs at the speed of a wave that has the SIMD to itself and the last at a third of it, whatever they hold.  A
+// frame ends with its last wave, so the wave with the longest chain of queries still ahead of it should be the one
+// that is served first.  Every wave publishes that figure -- the largest, over its lanes, of (rays per sample so far) x
+// (samples left) -- in its SIMD's row of a table in global memory, reads the rows' other entries and takes the level
+// its rank gives it.  Only which wave issues first changes: no pixel's arithmetic does.
+__device__ __forceinline__ void wave_priority_update(uint32_t *tab, uint32_t left) {
+  for (int off = 32; off > 0; off >>= 1) left = max(left, (uint32_t)__shfl_xor((int)left, off));
+  const uint32_t mine = (uint32_t)__builtin_amdgcn_readfirstlane((int)left) + 1u;  // (a live wave is never 0)
+  const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);  // HW_ID, XCC_ID
+  const uint32_t row = ((xcc & 15u) << 10) | (((hw >> 8) & 0xffu) << 2) | ((hw >> 4) & 3u);
+  const uint32_t col = hw & 15u;  // WAVE_ID: the wave's slot on its SIMD
+  uint32_t *rowp = tab + row * 16u;
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t other = 0u;
+  if (lane < 16u) other = __hip_atomic_load(rowp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == col) __hip_atomic_store(rowp + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool ahead = lane < 16u && lane != col && (other > mine || (other == mine && lane < col));
+  const int rank = __builtin_amdgcn_readfirstlane(__popcll(__builtin_amdgcn_ballot_w64(ahead)));
+  // (s_setprio takes an immediate and ignores EXEC: one scalar branch per level)
+  if (rank == 0) __builtin_amdgcn_s_setprio(3);
+  else if (rank == 1) __builtin_amdgcn_s_setprio(2);
+  else if (rank <= 3) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void wave_priority_leave(uint32_t *tab) {
+  const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);
+  const uint32_t row = ((xcc & 15u) << 10) | (((hw >> 8) & 0xffu) << 2) | ((hw >> 4) & 3u);
+  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(tab + row * 16u + (hw & 15u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 template <uint32_t F>
 __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &fr, const LaunchCfg &lc,
@@ -110,7 +154,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   const double inv_w = 1.0 / (double)fr.width, inv_h = 1.0 / (double)fr.height;
   const bool f32_jitter = w_pow2 && h_pow2 && fr.width <= (1 << 20) && fr.height <= (1 << 20);  // (wave-uniform)
   // per-lane pixel state
-  int32_t q32 = 0;  // the lane's work item (items < 2^31: make_frame); widened where it addresses memory
+  int32_t q32 = -1;  // the lane's work item (items < 2^31: make_frame); widened where it addresses memory; -1: none yet
   uint32_t work_px = 0;  // (cost probe) lane-steps of the mesh searches of this pixel's rays
   uint32_t ray_acc = 0;  // closest-hit queries of this lane's finished pixels, modulo what it has flushed (below)
   uint32_t pij = 0;  // the pixel's row << 16 | column (frames are below 65536 x 65536: make_frame)
@@ -194,8 +238,23 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
 #endif
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
             const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
+  uint32_t prio_tick = 0u;  // (wave-uniform)
   for (;;) {
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
+    if (lc.prio_tab != nullptr && (prio_tick++ & (uint32_t)(lc.prio_every - 1)) == 0u) {
+      // queries this lane's pixel still has to do, from its own rays per sample so far (+ 8 rays over one more sample:
+      // a pixel that has not started counts as an average one)
+      // -- with the scheduler's probe behind the launch, its tile's rays per sample stand in as 64 samples' worth of
+      // prior -- and, on a planned chain, what the probe said of the tiles still to come
+      float left = 0.f;
+      if (has_px && (active || k < fr.spp)) {
+        float prior_rays = 8.f, prior_n = 1.f;
+        if (lc.tile_cost != nullptr) prior_rays = 64.f * ((float)lc.tile_cost[q32 >> 6] * lc.rate_scale), prior_n = 64.f;
+        left = ((float)rays + prior_rays) * (float)(fr.spp - k + 1) * __builtin_amdgcn_rcpf((float)k + prior_n);
+        if (!(F & F_BVH) && lc.chain_next != nullptr) left += (float)lc.chain_fut[q32 >> 6];
+      }
+      wave_priority_update(lc.prio_tab, (uint32_t)fminf(left, 4.0e9f));
+    }
     // -------------------------------------------------------- sample / pixel bookkeeping
     if (!active && !done && has_px && k >= fr.spp) {
       const int64_t q = (int64_t)q32;
@@ -273,6 +332,18 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
             if (lc.probe_marks[item] >> 31) continue;  // a head item: not from this queue
             if (take_item(item)) cls = 1;
           }
+        }
+      }
+    } else if (!(F & F_BVH) && lc.chain_next != nullptr) {  // (wave-uniform) planned chains
+      if (!active && !done) {
+        while (!has_px && !done) {
+          const int gw = (int)((blockIdx.x * n_threads + threadIdx.x) >> 6);  // this wave in dispatch order
+          const int32_t t = q32 < 0 ? (gw < lc.n_chains ? (int32_t)lc.chain_first[gw] : -1) : lc.chain_next[q32 >> 6];
+          if (t < 0) {
+            done = true;
+            break;
+          }
+          (void)take_item((int64_t)t * 64 + (int64_t)(threadIdx.x & 63u));
         }
       }
     } else if (!active && !done) {
@@ -637,6 +708,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     RTMI_STAT(st.cyc[4] += stat_now() - tq2;)
   }
 
+  if (lc.prio_tab != nullptr) wave_priority_leave(lc.prio_tab);
   {  // total closest-hit queries: wave reduce, one atomic per wave
     unsigned long long ray_total = ray_acc;
     for (int off = 32; off > 0; off >>= 1) ray_total += __shfl_down(ray_total, off);
