@@ -70,6 +70,10 @@ def parse(argv=None):
     ap.add_argument("--probe-spp", type=int, default=0, help="rtmi_render_opts.probe_spp (0: library default)")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--rank-timeout", type=float, default=None,
+                    help="seconds after which the launcher (--gpus N started without torch.distributed.run) gives up on its ranks")
+    ap.add_argument("--selftest-die-rank", type=int, default=-1,
+                    help="with --selftest-exchange: this rank exits 3 before the exchange (launcher test)")
     ap.add_argument("--selftest-exchange", action="store_true",
                     help="CPU-only check of the launcher + the N-rank exchange (gloo, no rendering)")
     return ap.parse_args(argv)
@@ -311,28 +315,82 @@ def extra_line(tag, w, r, steps, shard=None):
             "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"], shard)}
 
 
-def shard_sweep(rtmi, torch, w, G, args):
+def shard_sweep(rtmi, torch, w, G, args, rounds=3, full_rounds=3):
     """T(full frame on one GPU) against T(each of the G shards on one GPU): rank r of G renders exactly shard r, so
-    max_r T(shard r) (+ the gather, bytes stated) is the G-GPU frame time a node can reach, measured here."""
-    rr = run_workload(rtmi, torch, None, w, args, 0, 1, False, 1, 1)  # warm-up loads the code object
-    full = {"kernel_ms": rr["kern_ms"], "rays": rr["rays_all"], "pixels": rr["pixels_rank"],
-            "resident_lanes": rr["shape"]["blocks"] * rr["shape"]["threads"]}
-    scene = rr["scene"]
+    max_r T(shard r) (+ the gather, bytes stated) is the G-GPU frame time a node can reach, measured here.  Single
+    renders scatter by a few per cent (which wave draws which pixel is left to atomics), so every shard is rendered
+    ``rounds`` times, the shards taking turns (0..G-1, 0..G-1, ...: no back-to-back repeats), and a shard's time is the
+    MEDIAN of its renders; a frame ends with its slowest rank, so the figure is T_full (median) / max_r median_r."""
+    from rtmi import scenes
+    H = W = w["size"]
+    seed = scenes.SCENE_SEEDS[w["scene"]]
+    scene = build_scene(rtmi.SceneBuilder(seed), w["scene"], W / H).commit()
+    opts = rtmi.render_opts(probe_spp=args.probe_spp) if args.probe_spp > 0 else None
+
+    def prepare(rank, world):
+        R = rtmi.Renderer(scene, H, W, w["spp"], w["depth"], True, rank=rank, world_size=world)
+        R.init_rng()
+        return R, R.states.clone()
+
+    def once(R, pristine):
+        R.states.copy_(pristine)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        R.render(opts=opts)
+        e1.record()
+        torch.cuda.synchronize()
+        R.check()
+        return e0.elapsed_time(e1)
+
+    Rf, pf = prepare(0, 1)
+    once(Rf, pf)  # warm-up loads the code object
+    full_ms = sorted(once(Rf, pf) for _ in range(full_rounds))
+    full_rays = Rf.total_rays()
+    shape = Rf.launch_shape(opts)
+    full = {"kernel_ms": full_ms[len(full_ms) // 2], "kernel_ms_min_max": [full_ms[0], full_ms[-1]], "renders": full_rounds,
+            "rays": float(full_rays), "pixels": H * W, "resident_lanes": shape["blocks"] * shape["threads"]}
+    del Rf, pf
+    rs = [prepare(r, G) for r in range(G)]
+    times = [[] for _ in range(G)]
+    for _ in range(rounds):
+        for r in range(G):
+            times[r].append(once(*rs[r]))
     shards = []
     for r in range(G):
-        x = run_workload(rtmi, torch, None, w, args, 0, 1, False, 1, 0, shard=(r, G), scene=scene)
-        lanes = x["shape"]["blocks"] * x["shape"]["threads"]
-        shards.append({"shard": r, "kernel_ms": x["kern_ms"], "rays": x["rays_all"], "pixels": x["pixels_rank"],
-                       "resident_lanes": lanes, "pixels_per_lane": x["pixels_rank"] / float(lanes),
-                       "mrays_per_s": x["rays_all"] / x["kern_ms"] / 1e3,
-                       "gather_bytes": x["items"] * 12})
+        R = rs[r][0]
+        sh = R.launch_shape(opts)
+        lanes = sh["blocks"] * sh["threads"]
+        t = sorted(times[r])
+        px = int((rtmi.pixel_map(R.frame) >= 0).sum())
+        rays = float(R.total_rays())
+        shards.append({"shard": r, "kernel_ms": t[len(t) // 2], "kernel_ms_min_max": [t[0], t[-1]], "renders": rounds,
+                       "rays": rays, "pixels": px, "resident_lanes": lanes, "pixels_per_lane": px / float(lanes),
+                       "mrays_per_s": rays / t[len(t) // 2] / 1e3, "gather_bytes": R.items * 12})
     worst = max(s_["kernel_ms"] for s_ in shards)
+    worst_single = max(s_["kernel_ms_min_max"][1] for s_ in shards)
     return {"workload": "%s: scenes/%s %dx%d x%dspp depth%d" % (w["name"], w["scene"], w["size"], w["size"], w["spp"], w["depth"]),
-            "G": G, "full_frame": full, "shards": shards, "max_shard_ms": worst,
+            "G": G, "full_frame": full, "shards": shards, "max_shard_ms": worst, "max_single_render_ms": worst_single,
             "predicted_speedup": full["kernel_ms"] / worst, "predicted_efficiency": full["kernel_ms"] / worst / G,
+            "predicted_speedup_worst_single_render": full["kernel_ms_min_max"][0] / worst_single,
             "ray_total_matches": abs(sum(s_["rays"] for s_ in shards) - full["rays"]) < 0.5,
-            "note": "kernel-only times on ONE GPU; the G-GPU step adds one gather of gather_bytes per rank to rank 0 "
-                    "(direct xGMI links, ~153 GB/s each) and the untile kernel"}
+            "note": "kernel-only times on ONE GPU, medians of %d renders per shard taken in turns (full frame: median of "
+                    "%d); predicted_speedup = T_full / max over shards of the shard's median; the G-GPU step adds one "
+                    "gather of gather_bytes per rank to rank 0 (direct xGMI links, ~153 GB/s each) and the untile kernel"
+                    % (rounds, full_rounds)}
+
+
+def sweep_digest(sw):
+    return {"workload": sw["workload"], "G": sw["G"], "full_frame_kernel_ms": sw["full_frame"]["kernel_ms"],
+            "full_frame_kernel_ms_min_max": sw["full_frame"]["kernel_ms_min_max"],
+            "shard_kernel_ms": [round(x["kernel_ms"], 2) for x in sw["shards"]],
+            "shard_kernel_ms_min": [round(x["kernel_ms_min_max"][0], 2) for x in sw["shards"]],
+            "shard_kernel_ms_max": [round(x["kernel_ms_min_max"][1], 2) for x in sw["shards"]],
+            "renders_per_shard": sw["shards"][0]["renders"],
+            "predicted_speedup": sw["predicted_speedup"],
+            "predicted_speedup_worst_single_render": sw["predicted_speedup_worst_single_render"],
+            "pixels_per_lane_per_shard": sw["shards"][0]["pixels_per_lane"],
+            "gather_bytes_per_rank": sw["shards"][0]["gather_bytes"], "ray_total_matches": sw["ray_total_matches"],
+            "note": sw["note"]}
 
 
 def selftest_exchange(args):
@@ -346,6 +404,8 @@ def selftest_exchange(args):
     rank, _, world = env_rank_world()
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if rank == args.selftest_die_rank:
+        raise SystemExit(3)  # a rank that dies before the rendezvous: the launcher must not wait for the others
     dist.init_process_group("gloo", rank=rank, world_size=world)
     h, w = 40, 56
     pm = shard_pixel_map(h, w, rank, world)
@@ -375,7 +435,7 @@ def main():
     if args.gpus > 1 and not launch.under_launcher():
         # become the launcher: N children, one per GPU, before this process touches a GPU
         rc = launch.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:],
-                                need_gpus=not args.selftest_exchange)
+                                need_gpus=not args.selftest_exchange, timeout=args.rank_timeout)
         raise SystemExit(rc)
     if args.selftest_exchange:
         if not launch.under_launcher():
@@ -453,13 +513,12 @@ def main():
         # what an 8-GPU node can reach on the N > 1 workload (C4), measured on this one GPU: full frame against each
         # of the eight shards (kernel only; the N-rank step adds one gather of ~6 MB per rank and the untile kernel)
         sw = shard_sweep(rtmi, torch, dict(WORKLOADS["c4"], name="c4"), 8, args)
+        # ... and on configs[4] (C5, birthday 4096^2 x 8192 spp: eight pixels per lane per shard; 25 s per full frame, so
+        # one render of it and of each shard)
+        sw5 = shard_sweep(rtmi, torch, dict(WORKLOADS["c5"], name="c5"), 8, args, rounds=1, full_rounds=1)
         if rank == 0:
-            out["config"]["shard_sweep"] = {
-                "workload": sw["workload"], "G": sw["G"], "full_frame_kernel_ms": sw["full_frame"]["kernel_ms"],
-                "shard_kernel_ms": [round(x["kernel_ms"], 2) for x in sw["shards"]],
-                "predicted_speedup": sw["predicted_speedup"], "pixels_per_lane_per_shard": sw["shards"][0]["pixels_per_lane"],
-                "gather_bytes_per_rank": sw["shards"][0]["gather_bytes"], "ray_total_matches": sw["ray_total_matches"],
-                "note": sw["note"]}
+            out["config"]["shard_sweep"] = sweep_digest(sw)
+            out["config"]["shard_sweep_c5"] = sweep_digest(sw5)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

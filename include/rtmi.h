@@ -220,7 +220,9 @@ int rtmi_untile_u32(const rtmi_frame *f, const uint32_t *d_all_counts, uint32_t 
 int rtmi_gather(void *nccl_comm, const rtmi_frame *f, const float *d_tiles, float *d_all_tiles, int root, void *stream);
 /* The reference's own decomposition (every rank renders the whole frame with GetWorkload's share of the samples,
  * post_process = 0): ncclReduce(sum) of the tile buffers into `root`, in place; follow with rtmi_untile and
- * rtmi_post_process.  comm NULL = one rank. */
+ * rtmi_post_process.  In that split every rank's frame is the whole frame, so the number of ranks is the
+ * communicator's, not the frame's: comm NULL means this rank is the only one (root must then be 0 and the call is a
+ * no-op); with a communicator, root must be one of its ranks (checked with ncclCommCount). */
 int rtmi_reduce_sum(void *nccl_comm, const rtmi_frame *f, float *d_tiles, int root, void *stream);
 
 /* GatherImageData's root-side step on a summed image (utils.cu:126-129):

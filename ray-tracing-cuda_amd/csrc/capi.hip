@@ -60,7 +60,8 @@ static RenderTuning default_tuning() {
     if (g_tune.promote < 0) g_tune.promote = 0;
     g_tune.probe_spp = env_int("RTMI_PROBE_SPP", 0);
     if (g_tune.probe_spp < 0 || g_tune.probe_spp > 64) g_tune.probe_spp = 0;
-    g_tune.plan = env_int("RTMI_PLAN", 1) ? 1 : 0;  // list frames: planned chains instead of the queue
+    g_tune.plan = env_int("RTMI_PLAN", 1);  // list frames: planned chains instead of the queue (0 never, 1 when waves have few tiles, 2 always)
+    if (g_tune.plan < 0 || g_tune.plan > 2) g_tune.plan = 1;
     g_tune.prio_every = env_int("RTMI_PRIO", 16);  // wave priorities: update interval in iterations (0: off)
     if (g_tune.prio_every < 0 || (g_tune.prio_every & (g_tune.prio_every - 1)) != 0) g_tune.prio_every = 16;
   });
@@ -564,15 +565,15 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 // [ quarters sorted ][ quarter order ][ 4 words ].  The counters come first so that
 // rtmi_render_status can find them from the scratch pointer alone.
 static constexpr size_t kCounterBytes = RTMI_COUNTER_WORDS * sizeof(unsigned long long);
+static constexpr int kMaxChains = 1 << 15;  // planned chains: one per wave of the grid (8 waves x 4 SIMDs x 1024 CUs)
 static size_t scratch_body_bytes(const FrameDev &d);
 static size_t scratch_bytes_of(const FrameDev &d) {
-  const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
   return scratch_body_bytes(d) + kPrioTabBytes + 2 * render_params_bytes();
 }
 static size_t scratch_body_bytes(const FrameDev &d) {
   const size_t n = (size_t)d.items, nt = (size_t)d.local_tiles;
   return (kCounterBytes + n * RTMI_STATE_WORDS * 4 + n * 4 + nt * 4 * 2 + 128 + (size_t)kHeadCap * 4 +
-         n * 4 + nt * 4 * 14 + 16 + 255) & ~(size_t)255;  // + the probe's work counts, the quarter-tile costs, their sorted
+         n * 4 + nt * 4 * 15 + 16 + (size_t)kMaxChains * 4 + 255) & ~(size_t)255;  // + the probe's work counts, the quarter-tile costs, their sorted
                                                      // list, the order, the chain plan; then the wave-priority table and
                                                      // the two kernel-argument blocks (scratch_bytes_of)
 }
@@ -741,6 +742,8 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_qcost = p_work + n, *p_qsorted = p_qcost + 4 * nt, *p_qmap = p_qsorted + 4 * nt, *p_qmax = p_qmap + 4 * nt;
     uint32_t *p_fut = p_qmax + 4;
     int32_t *p_next = reinterpret_cast<int32_t *>(p_fut + nt);
+    uint32_t *p_claims = reinterpret_cast<uint32_t *>(p_next + nt);
+    int32_t *p_first = reinterpret_cast<int32_t *>(p_claims + nt);  // kMaxChains words
     // mesh frames (binary32 t): the probe also books the lane-steps of its mesh searches on the pixels they serve
     static const bool cost_probe = env_int("RTMI_COST_PROBE", 1) != 0;
     const bool by_cost = cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
@@ -774,11 +777,20 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     plan.probe_spp = probe_spp;
     plan.tile_cost = p_cost;
     // list frames: planned chains instead of the queue (kernels.h: launch_chain_plan)
-    if (tune.plan && !(variant & F_BVH)) {
-      const int grid_waves = blocks * (threads / 64);
-      HIP_TRY(launch_chain_plan(p_order, p_cost, d.local_tiles, grid_waves, d.spp, probe_spp, p_next, p_fut, st));
-      plan.chain_next = p_next, plan.chain_fut = p_fut, plan.chain_first = p_order;
-      plan.n_chains = grid_waves < d.local_tiles ? grid_waves : d.local_tiles;
+    // -- when a wave has few tiles to render (at most three on average: a 2048^2 frame over eight GPUs has 1.33, C2 2.67).
+    // With more the queue evens out what the probe mis-estimates better than a plan can foresee it (spheres 1024^2 x 64 spp,
+    // four tiles per wave: 24.7 ms planned against 22.2 from the queue; C5's shards, eight per wave: the same either way).
+    const int grid_waves = blocks * (threads / 64);
+    if (tune.plan && prio && !(variant & F_BVH) && (tune.plan == 2 || (int64_t)d.local_tiles <= 3 * (int64_t)grid_waves)) {
+      const int simds = ls.n_cu * 4 < grid_waves ? ls.n_cu * 4 : grid_waves;  // (four SIMDs per compute unit)
+      const int rounds = (grid_waves + simds - 1) / simds;
+      if (simds * rounds <= kMaxChains) {
+        HIP_TRY(launch_chain_plan(p_order, p_cost, d.local_tiles, simds, rounds, d.spp, probe_spp, p_first, p_next, p_fut, st));
+        HIP_TRY(hipMemsetAsync(p_claims, 0, nt * 4, st));
+        plan.chain_next = p_next, plan.chain_fut = p_fut, plan.chain_first = p_first, plan.claims = p_claims;
+        plan.plan_simds = simds, plan.plan_rounds = rounds;
+        plan.tile_order = p_order;  // (per tile in this mode: the take-over's order)
+      }
     }
   }
   HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
@@ -842,21 +854,29 @@ struct Rccl {
   decltype(&ncclRecv) recv = nullptr;
   decltype(&ncclReduce) reduce = nullptr;
   decltype(&ncclGetErrorString) err = nullptr;
+  decltype(&ncclCommCount) count = nullptr;
   bool ok = false;
 };
 const Rccl &rccl() {
   static const Rccl r = [] {
     Rccl x;
+    // "already in the process" and "the handle to look symbols up in" are two things: RTLD_DEFAULT is a null handle
+    // on glibc, so a found symbol must not be mistaken for a failed dlopen (which once pulled a SECOND copy of RCCL
+    // in next to the one the caller's communicator came from)
+    const bool in_process = dlsym(RTLD_DEFAULT, "ncclSend") != nullptr;
     void *h = RTLD_DEFAULT;
-    if (!dlsym(h, "ncclSend")) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-    if (!h) return x;
+    if (!in_process) {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) return x;
+    }
     x.group_start = reinterpret_cast<decltype(x.group_start)>(dlsym(h, "ncclGroupStart"));
     x.group_end = reinterpret_cast<decltype(x.group_end)>(dlsym(h, "ncclGroupEnd"));
     x.send = reinterpret_cast<decltype(x.send)>(dlsym(h, "ncclSend"));
     x.recv = reinterpret_cast<decltype(x.recv)>(dlsym(h, "ncclRecv"));
     x.reduce = reinterpret_cast<decltype(x.reduce)>(dlsym(h, "ncclReduce"));
     x.err = reinterpret_cast<decltype(x.err)>(dlsym(h, "ncclGetErrorString"));
+    x.count = reinterpret_cast<decltype(x.count)>(dlsym(h, "ncclCommCount"));
     x.ok = x.group_start && x.group_end && x.send && x.recv && x.reduce;
     return x;
   }();
@@ -886,26 +906,42 @@ int rtmi_gather(void *nccl_comm, const rtmi_frame *f, const float *d_tiles, floa
   const Rccl &R = rccl();
   if (!R.ok) return fail(RTMI_ERR_NO_DEVICE, "RCCL (librccl.so.1) is not available in this process");
   ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
-  // xGMI is point to point and every peer has a direct link to the root: one grouped round of sends, no ring
+  // xGMI is point to point and every peer has a direct link to the root: one grouped round of sends, no ring.
+  // A group that was opened is always closed, also when a send / recv inside it fails: the communicator must not be
+  // left mid-group for the caller's next collective.
   RCCL_TRY(R.group_start());
+  ncclResult_t first = ncclSuccess;
+  const char *what = "";
   if (d.rank == root) {
-    for (int r = 0; r < d.world; r++)
-      if (r != root) RCCL_TRY(R.recv(d_all_tiles + (size_t)r * count, count, ncclFloat, r, comm, st));
+    for (int r = 0; r < d.world && first == ncclSuccess; r++)
+      if (r != root) first = R.recv(d_all_tiles + (size_t)r * count, count, ncclFloat, r, comm, st), what = "ncclRecv";
   } else {
-    RCCL_TRY(R.send(d_tiles, count, ncclFloat, root, comm, st));
+    first = R.send(d_tiles, count, ncclFloat, root, comm, st), what = "ncclSend";
   }
-  RCCL_TRY(R.group_end());
+  const ncclResult_t closed = R.group_end();
+  if (first != ncclSuccess) return rccl_fail(R, first, what);
+  if (closed != ncclSuccess) return rccl_fail(R, closed, "ncclGroupEnd");
   return RTMI_OK;
 }
 
 int rtmi_reduce_sum(void *nccl_comm, const rtmi_frame *f, float *d_tiles, int root, void *stream) {
   FrameDev d;
   if (!make_frame(f, &d) || !d_tiles || root < 0) return fail(RTMI_ERR_INVALID, "bad reduce arguments");
-  if (!nccl_comm) return RTMI_OK;  // a single rank: its sum is the sum
+  // In the reference's sample split every rank renders the WHOLE frame (utils.cu:189,216-221), so the frame says nothing
+  // about how many ranks there are: the communicator does.  NULL = this rank is the only one, its sum is the sum.
+  if (!nccl_comm) {
+    if (root != 0) return fail(RTMI_ERR_INVALID, "reduce without a communicator is a single rank: root must be 0");
+    return RTMI_OK;
+  }
   const Rccl &R = rccl();
   if (!R.ok) return fail(RTMI_ERR_NO_DEVICE, "RCCL (librccl.so.1) is not available in this process");
-  RCCL_TRY(R.reduce(d_tiles, d_tiles, (size_t)d.items * 3, ncclFloat, ncclSum, root, reinterpret_cast<ncclComm_t>(nccl_comm),
-                    (hipStream_t)stream));
+  ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+  if (R.count) {
+    int n = 0;
+    RCCL_TRY(R.count(comm, &n));
+    if (root >= n) return fail(RTMI_ERR_INVALID, "reduce root is not a rank of the communicator");
+  }
+  RCCL_TRY(R.reduce(d_tiles, d_tiles, (size_t)d.items * 3, ncclFloat, ncclSum, root, comm, (hipStream_t)stream));
   return RTMI_OK;
 }
 

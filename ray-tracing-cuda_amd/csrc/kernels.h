@@ -49,11 +49,12 @@ struct SchedPlan {
   int probe_spp = 2;                       // samples per pixel of the probe behind these (thresholds: sparse_items[23..25])
   uint32_t *prio_tab = nullptr;            // optional: the wave-priority table (render_body.h: kPrioRows x 16 words, zeroed)
   const uint32_t *tile_cost = nullptr;     // optional: the probe's ray count per tile (launch_tile_order's d_cost)
-  // planned chains (launch_chain_plan): all three or none
+  // planned chains (launch_chain_plan): all or none; with them tile_order is per TILE and prio_tab is required
   const int32_t *chain_next = nullptr;
   const uint32_t *chain_fut = nullptr;
-  const uint32_t *chain_first = nullptr;   // (= the longest-first tile order)
-  int n_chains = 0;
+  const int32_t *chain_first = nullptr;
+  uint32_t *claims = nullptr;              // one word per tile, zeroed
+  int plan_simds = 0, plan_rounds = 0;
 };
 constexpr size_t kPrioTabBytes = (size_t)(1 << 14) * 16 * sizeof(uint32_t);
 // d_params: render_params_bytes() of device memory that stays untouched until the launch has finished (the kernel's
@@ -79,12 +80,14 @@ hipError_t launch_tile_order(uint32_t *d_ray_counts, int n_tiles, uint32_t *d_co
 hipError_t launch_quarter_order(const uint32_t *d_order, const uint32_t *d_work, const uint32_t *d_rays, int n_tiles,
                                 uint32_t *d_qcost, uint32_t *d_qsorted, uint32_t *d_qmax, uint32_t *d_qmap, hipStream_t stream);
 
-// Planned chains for list frames: the tiles in longest-first order (d_order) are dealt to the grid's waves in a snake
-// -- wave w of W gets ranks w, 2W - 1 - w, 2W + w, ... -- so that every wave's chain costs about the same (ranks beyond
-// the first round pair the lightest tiles with the lightest first tiles).  d_next[tile] = the tile after it in its
-// chain (-1: none), d_fut[tile] = estimated queries per lane of the tiles after it: d_cost x spp / (64 probe_spp).
-hipError_t launch_chain_plan(const uint32_t *d_order, const uint32_t *d_cost, int n_tiles, int grid_waves, int spp,
-                             int probe_spp, int32_t *d_next, uint32_t *d_fut, hipStream_t stream);
+// Planned chains for list frames.  The tiles in longest-first order (d_order) are dealt to the SIMDs in a snake -- SIMD s of
+// S gets ranks s, 2S - 1 - s, 2S + s, ... -- so that every SIMD's share costs about the same, and a SIMD's share is dealt
+// to its R waves in a snake again (its k-th tile goes to wave k, 2R - 1 - k, 2R + k, ...: the lightest first tiles are
+// paired with the tiles of the second round).  Chain c = wave * S + SIMD.  d_first[c] = its first tile or -1,
+// d_next[tile] = the tile after it in its chain (-1: none), d_fut[tile] = estimated queries per lane of the tiles after
+// it: d_cost x spp / (64 probe_spp).  Which wave of which SIMD a wave IS it finds out when it starts (render_body.h).
+hipError_t launch_chain_plan(const uint32_t *d_order, const uint32_t *d_cost, int n_tiles, int simds, int rounds, int spp,
+                             int probe_spp, int32_t *d_first, int32_t *d_next, uint32_t *d_fut, hipStream_t stream);
 
 hipError_t launch_untile(const FrameDev &fr, const float *d_tiles, float *d_image, hipStream_t stream);
 hipError_t launch_untile_u32(const FrameDev &fr, const uint32_t *d_tiles, uint32_t *d_image, hipStream_t stream);

@@ -398,32 +398,37 @@ hipError_t launch_quarter_order(const uint32_t *d_order, const uint32_t *d_work,
   return hipGetLastError();
 }
 
-// One thread per wave of the render grid: its chain (ranks k W + (k odd ? W - 1 - w : w) of the longest-first
-// order), walked backwards so that every tile learns what follows it.
+// One thread per chain (wave r of SIMD s, c = r S + s), walked backwards so that every tile learns what follows it.
+// The SIMD's k-th tile is rank k S + (k odd ? S - 1 - s : s); the wave's j-th tile is the SIMD's k = j R + (j odd ? R - 1 - r : r).
 __global__ __launch_bounds__(256) void chain_link_kernel(const uint32_t *__restrict__ order, const uint32_t *__restrict__ cost,
-                                                          int n_tiles, int n_waves, float scale, int32_t *__restrict__ next,
-                                                          uint32_t *__restrict__ fut) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_waves || w >= n_tiles) return;
-  auto rank = [&](int k) -> int64_t { return (int64_t)k * n_waves + ((k & 1) ? n_waves - 1 - w : w); };
+                                                          int n_tiles, int S, int R, float scale, int32_t *__restrict__ first,
+                                                          int32_t *__restrict__ next, uint32_t *__restrict__ fut) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= S * R) return;
+  const int s = c % S, r = c / S;
+  auto rank = [&](int j) -> int64_t {
+    const int64_t k = (int64_t)j * R + ((j & 1) ? R - 1 - r : r);
+    return k * S + ((k & 1) ? S - 1 - s : s);
+  };
   int steps = 0;
   while (rank(steps) < n_tiles) steps++;
   float acc = 0.f;
   int32_t after = -1;
-  for (int k = steps - 1; k >= 0; k--) {
-    const uint32_t t = order[rank(k)];
+  for (int j = steps - 1; j >= 0; j--) {
+    const uint32_t t = order[rank(j)];
     next[t] = after;
     fut[t] = (uint32_t)fminf(acc, 4.0e9f);
     acc += (float)cost[t] * scale;
     after = (int32_t)t;
   }
+  first[c] = after;
 }
-hipError_t launch_chain_plan(const uint32_t *d_order, const uint32_t *d_cost, int n_tiles, int grid_waves, int spp,
-                             int probe_spp, int32_t *d_next, uint32_t *d_fut, hipStream_t stream) {
-  const int n = grid_waves < n_tiles ? grid_waves : n_tiles;
+hipError_t launch_chain_plan(const uint32_t *d_order, const uint32_t *d_cost, int n_tiles, int simds, int rounds, int spp,
+                             int probe_spp, int32_t *d_first, int32_t *d_next, uint32_t *d_fut, hipStream_t stream) {
+  const int n = simds * rounds;
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(chain_link_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_order, d_cost, n_tiles, grid_waves,
-                     (float)spp / (64.f * (float)probe_spp), d_next, d_fut);
+  hipLaunchKernelGGL(chain_link_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_order, d_cost, n_tiles, simds, rounds,
+                     (float)spp / (64.f * (float)probe_spp), d_first, d_next, d_fut);
   return hipGetLastError();
 }
 
@@ -615,8 +620,9 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.prio_tab = probe ? nullptr : plan.prio_tab;
   lc.tile_cost = plan.tile_cost;
   lc.rate_scale = 1.f / (64.f * (float)(plan.probe_spp > 0 ? plan.probe_spp : 1));
-  lc.chain_next = (F & F_BVH) ? nullptr : plan.chain_next;
-  lc.chain_fut = plan.chain_fut, lc.chain_first = plan.chain_first, lc.n_chains = plan.n_chains;
+  lc.chain_next = (F & F_BVH) || lc.prio_tab == nullptr ? nullptr : plan.chain_next;
+  lc.chain_fut = plan.chain_fut, lc.chain_first = plan.chain_first, lc.claims = plan.claims;
+  lc.plan_simds = plan.plan_simds, lc.plan_rounds = plan.plan_rounds;
   lc.prio_every = tune.prio_every > 0 ? tune.prio_every : 16;
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)

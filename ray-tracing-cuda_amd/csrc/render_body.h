@@ -36,12 +36,18 @@ struct LaunchCfg {
   int32_t prio_every;            // with prio_tab: a wave looks at its priority every this many iterations (power of two)
   uint32_t *prio_tab;            // optional: kPrioRows x 16 words, zeroed per launch -- per SIMD (row: XCC | SE | SH | CU | SIMD
                                  // of HW_ID) and wave slot (column: HW_ID.WAVE_ID), the queries the wave still has to do
-  // Planned chains (list variants; kernels.hip: chain_link_kernel): instead of the queue every wave walks a chain of
-  // tiles fixed before the launch, lane l rendering pixel l of each.
-  const int32_t *chain_next;     // optional: per local tile, the tile that follows it in its wave's chain, -1: the last
-  const uint32_t *chain_fut;     // with chain_next: per tile, estimated queries per lane of the tiles after it in its chain
-  const uint32_t *chain_first;   // with chain_next: wave w (dispatch order) starts on tile chain_first[w] (w < n_chains)
-  int32_t n_chains;              // waves that have a chain (min(waves of the grid, local tiles))
+  // Planned chains (list variants with prio_tab; kernels.hip: chain_link_kernel): instead of the queue every wave walks
+  // a chain of tiles fixed before the launch, lane l rendering pixel l of each.  The chains are laid out per SIMD: a
+  // wave learns at its start which SIMD it runs on and how many waves came there before it (prio_tab columns 14, 15),
+  // SIMDs are numbered in order of arrival (counters[35]), and chain `round x plan_simds + simd` is the wave's.
+  const int32_t *chain_next;     // optional: per local tile, the tile that follows it in its chain, -1: the last
+  const uint32_t *chain_fut;     // per tile, estimated queries per lane of the tiles after it in its chain
+  const int32_t *chain_first;    // per chain, its first tile (-1: an empty chain)
+  int32_t plan_simds, plan_rounds;  // the plan's shape: SIMDs x waves per SIMD
+  uint32_t *claims;              // one word per local tile, zeroed per launch: the wave (index + 1) that renders it.  A
+                                 // wave that has nothing left takes the lightest tile nobody has started (cursor:
+                                 // counters[36], from the far end of tile_order, which in this mode is per TILE), so
+                                 // every tile is rendered whatever the hardware's placement of the waves was
   const uint32_t *tile_cost;     // optional: the probe's ray count per tile (64 pixels x probe_spp samples): a pixel's
   float rate_scale;              // rays per sample are first taken as tile_cost x rate_scale = 1 / (64 probe_spp)
 };
@@ -63,15 +69,37 @@ __device__ __forceinline__ void wave_priority_update(uint32_t *tab, uint32_t lef
   uint32_t *rowp = tab + row * 16u;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t other = 0u;
-  if (lane < 16u) other = __hip_atomic_load(rowp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (columns 0..11: WAVE_ID is below 10 on this part; 14 and 15 belong to the planned chains' registration)
+  if (lane < 12u) other = __hip_atomic_load(rowp + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (lane == col) __hip_atomic_store(rowp + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const bool ahead = lane < 16u && lane != col && (other > mine || (other == mine && lane < col));
+  const bool ahead = lane < 12u && lane != col && (other > mine || (other == mine && lane < col));
   const int rank = __builtin_amdgcn_readfirstlane(__popcll(__builtin_amdgcn_ballot_w64(ahead)));
   // (s_setprio takes an immediate and ignores EXEC: one scalar branch per level)
   if (rank == 0) __builtin_amdgcn_s_setprio(3);
   else if (rank == 1) __builtin_amdgcn_s_setprio(2);
   else if (rank <= 3) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
+}
+// Planned chains: which chain is this wave's?  Column 15 of its SIMD's row counts the waves that have arrived there,
+// column 14 holds the SIMD's number + 1 once its first wave has drawn one (the others wait for it: that wave is
+// resident and a few instructions away from the store).  -1: the plan has no chain for this wave.
+__device__ __forceinline__ int wave_chain_id(uint32_t *tab, unsigned long long *simd_counter, int plan_simds, int plan_rounds) {
+  const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);
+  const uint32_t row = ((xcc & 15u) << 10) | (((hw >> 8) & 0xffu) << 2) | ((hw >> 4) & 3u);
+  uint32_t *rowp = tab + row * 16u;
+  uint32_t round = 0u, simd = 0u;
+  if ((threadIdx.x & 63u) == 0u) {
+    round = atomicAdd(rowp + 15, 1u);
+    if (round == 0u) {
+      simd = (uint32_t)atomicAdd(simd_counter, 1ull);
+      __hip_atomic_store(rowp + 14, simd + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while ((simd = __hip_atomic_load(rowp + 14, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(2);
+      simd -= 1u;
+    }
+  }
+  round = (uint32_t)__builtin_amdgcn_readfirstlane((int)round), simd = (uint32_t)__builtin_amdgcn_readfirstlane((int)simd);
+  return (round < (uint32_t)plan_rounds && simd < (uint32_t)plan_simds) ? (int)(round * (uint32_t)plan_simds + simd) : -1;
 }
 __device__ __forceinline__ void wave_priority_leave(uint32_t *tab) {
   const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);
@@ -239,6 +267,17 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
             const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
   uint32_t prio_tick = 0u;  // (wave-uniform)
+  if (!(F & F_BVH) && lc.chain_next != nullptr) {  // planned chains: this wave's chain and its first tile
+    const int chain = wave_chain_id(lc.prio_tab, counters + 35, lc.plan_simds, lc.plan_rounds);
+    const int32_t t = chain >= 0 ? lc.chain_first[chain] : -1;
+    heavy = t < 0;
+    if (t >= 0) {
+      q32 = t * 64 + (int32_t)(threadIdx.x & 63u);
+      uint32_t was = 1u;
+      if ((threadIdx.x & 63u) == 0u) was = atomicCAS(&lc.claims[t], 0u, ((blockIdx.x * n_threads + threadIdx.x) >> 6) + 1u);
+      if (__builtin_amdgcn_readfirstlane((int)was) == 0) (void)take_item((int64_t)q32);
+    }
+  }
   for (;;) {
     RTMI_STAT(const unsigned long long tq0 = stat_now();)
     if (lc.prio_tab != nullptr && (prio_tick++ & (uint32_t)(lc.prio_every - 1)) == 0u) {
@@ -251,7 +290,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         float prior_rays = 8.f, prior_n = 1.f;
         if (lc.tile_cost != nullptr) prior_rays = 64.f * ((float)lc.tile_cost[q32 >> 6] * lc.rate_scale), prior_n = 64.f;
         left = ((float)rays + prior_rays) * (float)(fr.spp - k + 1) * __builtin_amdgcn_rcpf((float)k + prior_n);
-        if (!(F & F_BVH) && lc.chain_next != nullptr) left += (float)lc.chain_fut[q32 >> 6];
+        if (!(F & F_BVH) && lc.chain_next != nullptr && !heavy) left += (float)lc.chain_fut[q32 >> 6];
       }
       wave_priority_update(lc.prio_tab, (uint32_t)fminf(left, 4.0e9f));
     }
@@ -335,15 +374,35 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         }
       }
     } else if (!(F & F_BVH) && lc.chain_next != nullptr) {  // (wave-uniform) planned chains
-      if (!active && !done) {
-        while (!has_px && !done) {
-          const int gw = (int)((blockIdx.x * n_threads + threadIdx.x) >> 6);  // this wave in dispatch order
-          const int32_t t = q32 < 0 ? (gw < lc.n_chains ? (int32_t)lc.chain_first[gw] : -1) : lc.chain_next[q32 >> 6];
+      const uint32_t me = ((blockIdx.x * n_threads + threadIdx.x) >> 6) + 1u;  // this wave's mark in `claims`
+      if (!active && !has_px && !heavy) {  // (`heavy` in this mode: the lane has walked its chain to the end)
+        for (;;) {
+          const int32_t t = lc.chain_next[q32 >> 6];
           if (t < 0) {
+            heavy = true;
+            break;
+          }
+          q32 = t * 64 + (int32_t)(threadIdx.x & 63u);  // (the walk goes on from here also when another wave has the tile)
+          const uint32_t was = atomicCAS(&lc.claims[t], 0u, me);
+          if ((was == 0u || was == me) && take_item((int64_t)q32)) break;
+        }
+      }
+      // every lane idle, every chain walked: the wave takes over tiles nobody has started, lightest first
+      if (!done && __builtin_amdgcn_ballot_w64(active || has_px || !heavy) == 0ull) {
+        for (;;) {
+          unsigned long long c = 0ull;
+          if ((threadIdx.x & 63u) == 0u) c = atomicAdd(&counters[36], 1ull);
+          const int ci = __builtin_amdgcn_readfirstlane((int)(c < (unsigned long long)fr.local_tiles ? c : (unsigned long long)fr.local_tiles));
+          if (ci >= fr.local_tiles) {
             done = true;
             break;
           }
+          const int32_t t = (int32_t)lc.tile_order[fr.local_tiles - 1 - ci];
+          uint32_t was = 1u;
+          if ((threadIdx.x & 63u) == 0u) was = atomicCAS(&lc.claims[t], 0u, me);
+          if (__builtin_amdgcn_readfirstlane((int)was) != 0) continue;
           (void)take_item((int64_t)t * 64 + (int64_t)(threadIdx.x & 63u));
+          if (__builtin_amdgcn_ballot_w64(has_px) != 0ull) break;  // (a tile of padding only: look further)
         }
       }
     } else if (!active && !done) {
@@ -737,6 +796,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       // per wave (tools/gpu_shard_waves.py): lifetime in shader cycles, queries, start and end on the 100 MHz clock
       g_wave_stats[wid][0] = life, g_wave_stats[wid][11] = wave_queries;
       g_wave_stats[wid][12] = t_begin_rt, g_wave_stats[wid][13] = __builtin_amdgcn_s_memrealtime();
+      g_wave_stats[wid][14] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);
     } else if (wid < 16384u) {
       g_wave_stats[wid][0] = life;
 #if RTMI_STATS != 9

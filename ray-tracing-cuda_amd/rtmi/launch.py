@@ -36,16 +36,22 @@ def visible_gpus():
     return torch.cuda.device_count()
 
 
-def spawn_ranks(n, script, argv, need_gpus=True, timeout=None):
+def spawn_ranks(n, script, argv, need_gpus=True, timeout=None, poll_s=0.05):
     """Start ``n`` ranks of ``script argv`` on this node and wait for them.
 
-    Returns the worst exit code (0 only when every rank exited 0).  Raises SystemExit with a
-    clear message when ``need_gpus`` and fewer than ``n`` GPUs are visible."""
+    Returns the worst exit code (0 only when every rank exited 0).  All children are watched together: as soon as one
+    of them exits non-zero (or is killed) the others -- which would sit in a collective waiting for it until the
+    driver's limit -- are terminated and its code is returned; ``timeout`` (seconds, also ``--rank-timeout`` of
+    bench.py / RTMI_RANK_TIMEOUT) bounds the whole job and yields 124.  Raises SystemExit with a clear message when
+    ``need_gpus`` and fewer than ``n`` GPUs are visible."""
+    import time
     if need_gpus:
         have = visible_gpus()
         if have < n:
             raise SystemExit("--gpus %d requested but only %d GPU(s) are visible: refusing to run fewer ranks"
                              % (n, have))
+    if timeout is None and os.environ.get("RTMI_RANK_TIMEOUT"):
+        timeout = float(os.environ["RTMI_RANK_TIMEOUT"])
     port = int(os.environ.get("MASTER_PORT", "0")) or free_port()
     procs = []
     for r in range(n):
@@ -55,15 +61,32 @@ def spawn_ranks(n, script, argv, need_gpus=True, timeout=None):
                     "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")})
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
     worst = 0
+    t0 = time.monotonic()
     try:
-        for p in procs:
-            rc = p.wait(timeout=timeout)
-            if rc != 0:
-                worst = worst or rc
-    except subprocess.TimeoutExpired:
-        worst = 124
+        live = list(procs)
+        while live:
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+            if worst:
+                break  # a rank failed: the rest cannot finish their collectives
+            if timeout is not None and time.monotonic() - t0 > timeout:
+                worst = 124
+                break
+            if live:
+                time.sleep(poll_s)
     finally:
         for p in procs:  # exactly the children started here, by PID
             if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
                 p.kill()
+                p.wait()
     return worst

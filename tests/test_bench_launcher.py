@@ -47,3 +47,29 @@ def test_world_size_mismatch_is_an_error():
              env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
                         "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "WORLD_SIZE=1 but --gpus 4" in (r.stdout + r.stderr)
+
+
+def test_a_rank_that_dies_takes_the_job_down_at_once():
+    """One rank exits before the rendezvous: the others would wait in init_process_group for the store's timeout
+    (minutes); the launcher sees the death, terminates them and returns the dead rank's code."""
+    import time
+    t0 = time.time()
+    r = _run(["--gpus", "3", "--selftest-exchange", "--selftest-die-rank", "1"], timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stdout + r.stderr)
+    assert time.time() - t0 < 60
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_rank_timeout_bounds_the_job():
+    """--rank-timeout: ranks that hang (here: rank 0 alone waits for a peer that was told a different port) are
+    terminated and the launcher returns 124."""
+    sys.path.insert(0, os.path.join(ROOT, "ray-tracing-cuda_amd"))
+    from rtmi import launch
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write("import time\ntime.sleep(600)\n")
+    try:
+        rc = launch.spawn_ranks(2, f.name, [], need_gpus=False, timeout=1.0)
+    finally:
+        os.unlink(f.name)
+    assert rc == 124

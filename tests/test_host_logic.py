@@ -310,9 +310,13 @@ def test_render_opts_validation():
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(ok), dummy, dummy, None, None) == -1
     assert b"not committed" in L.rtmi_last_error()  # the options passed; the scene is what is missing
     # the call's counters + states copy + probe counts + tile costs and order + 32 words + the head list (16,384 entries)
-    # + the probe's work counts + per quarter tile: cost, sorted list, order (4 each per tile) + 4 words
-    assert L.rtmi_render_scratch_bytes(C.byref(fr)) == 40 * 8 + 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 128 + 16384 * 4 + \
-        64 * 4 + 1 * 4 * 12 + 16
+    # + the probe's work counts + per quarter tile: cost, sorted list, order (4 each per tile) + 4 words + the chain
+    # plan (per tile: what follows, its estimate, who renders it; per chain its first tile), rounded up to 256;
+    # then the wave-priority table (2^14 SIMD rows of 16 words) and two kernel-argument blocks
+    body = (40 * 8 + 64 * 6 * 4 + 64 * 4 + 1 * 4 * 2 + 128 + 16384 * 4 + 64 * 4 + 1 * 4 * 15 + 16 + 32768 * 4 + 255) & ~255
+    total = L.rtmi_render_scratch_bytes(C.byref(fr))
+    params = (total - body - (1 << 14) * 16 * 4) // 2
+    assert total == body + (1 << 14) * 16 * 4 + 2 * params and params % 256 == 0 and 512 <= params <= 2048, (total, body, params)
 
 
 def test_no_cpu_fallback():

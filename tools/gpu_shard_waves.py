@@ -67,7 +67,7 @@ d = {"workload": wl, "shard": [r, G], "spp": w["spp"], "probe_spp": prio, "shape
 T = end.max()
 bins = np.linspace(0, T, 21)
 d["live_waves_at"] = [int(((beg <= t) & (end > t)).sum()) for t in bins[:-1]]
-tag = "%s_s%dof%d_p%d_b%d" % (wl, r, G, prio, bpc)
+tag = "%s_s%dof%d_p%d_b%d%s" % (wl, r, G, prio, bpc, os.environ.get("RTMI_TOOL_TAG", ""))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.savez_compressed(os.path.join(ROOT, "gpurun_out", "shard_waves_%s.npz" % tag), ws=ws, counts=counts.astype(np.uint32))
 print(json.dumps(d))
