@@ -340,12 +340,13 @@ def shard_sweep(rtmi, torch, w, G, args, rounds=3, full_rounds=3):
         e1.record()
         torch.cuda.synchronize()
         R.check()
+        R.last_rays = R.total_rays()  # (the scene's counters are those of its most recent render: read them now)
         return e0.elapsed_time(e1)
 
     Rf, pf = prepare(0, 1)
     once(Rf, pf)  # warm-up loads the code object
     full_ms = sorted(once(Rf, pf) for _ in range(full_rounds))
-    full_rays = Rf.total_rays()
+    full_rays = Rf.last_rays
     shape = Rf.launch_shape(opts)
     full = {"kernel_ms": full_ms[len(full_ms) // 2], "kernel_ms_min_max": [full_ms[0], full_ms[-1]], "renders": full_rounds,
             "rays": float(full_rays), "pixels": H * W, "resident_lanes": shape["blocks"] * shape["threads"]}
@@ -362,7 +363,7 @@ def shard_sweep(rtmi, torch, w, G, args, rounds=3, full_rounds=3):
         lanes = sh["blocks"] * sh["threads"]
         t = sorted(times[r])
         px = int((rtmi.pixel_map(R.frame) >= 0).sum())
-        rays = float(R.total_rays())
+        rays = float(R.last_rays)
         shards.append({"shard": r, "kernel_ms": t[len(t) // 2], "kernel_ms_min_max": [t[0], t[-1]], "renders": rounds,
                        "rays": rays, "pixels": px, "resident_lanes": lanes, "pixels_per_lane": px / float(lanes),
                        "mrays_per_s": rays / t[len(t) // 2] / 1e3, "gather_bytes": R.items * 12})
