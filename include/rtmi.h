@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define RTMI_VERSION 2
+#define RTMI_VERSION 3
 #define RTMI_TILE 8            /* tile edge in pixels; 64 work items per tile = one wavefront */
 #define RTMI_STATE_WORDS 6     /* live words of curandState: d, v[0..4] */
 
@@ -63,8 +63,8 @@ typedef struct rtmi_scene rtmi_scene; /* opaque; replaces the device-resident Hi
  * arguments of PathTracing (ray_tracing.cuh:19-21) and the rank/world_size of
  * DistributedMain (utils.cu:186-189). */
 typedef struct rtmi_frame {
-  int32_t height;
-  int32_t width;
+  int32_t height;       /* 1 .. RTMI_MAX_EXTENT (the reference has no such limit: a pixel's row and column share one */
+  int32_t width;        /* 32-bit register of the trace kernel); a larger frame is refused with RTMI_ERR_INVALID */
   int32_t spp;          /* samples per pixel rendered by THIS call */
   int32_t max_depth;    /* TRACE_DEPTH_LIMIT, ray_tracing.cu:10,23 */
   int32_t post_process; /* 1: out = sqrt(clamp(sum/spp,0,1)) (ray_tracing.cu:78-83); 0: raw sum */
@@ -72,6 +72,7 @@ typedef struct rtmi_frame {
   int32_t world_size;   /* number of shards (GPUs) */
 } rtmi_frame;
 
+#define RTMI_MAX_EXTENT 65535
 const char *rtmi_last_error(void);
 int rtmi_version(void);
 /* Number of usable GPUs (0 when there is none); never fails. */
@@ -273,7 +274,20 @@ typedef struct rtmi_render_opts {
   int32_t probe_spp;         /* 0 default (2): samples per pixel of the scheduler's cost probe, 1..64 */
   int32_t head_pct[3];       /* 0 default (80, 55, 30): mesh frames, per cent of the frame's largest probe count from
                               * which a pixel gets a wave to itself / shares one with another / gets one lane in 16 */
-  int32_t reserved;
+  int32_t plan;              /* -1 default (1).  List scenes (no mesh) with a probe behind the launch: 0 = every lane takes its
+                              * pixels from the work queue; 1 = when the grid's waves have at most three tiles each, every
+                              * wave walks a CHAIN of tiles planned before the launch (tiles dealt to the SIMDs, then to a
+                              * SIMD's waves, in snakes over the longest-first order, so that all chains of a SIMD and all
+                              * SIMDs cost about the same; needs wave_priority); 2 = chains for any number of tiles */
+  int32_t wave_priority;     /* -1 default (16); 0 = the hardware's oldest-wave-first issue order; N (a power of two) = every
+                              * N iterations a wave publishes how many queries it still has to do and takes the s_setprio
+                              * level its rank among the waves of its SIMD gives it (longest remaining chain first) */
+  int32_t lane_stride;       /* 0 default: list scenes, a frame with fewer pixels than the grid has lanes is spread thin, one
+                              * pixel per 2 / 4 / 8 / 16 lanes as far as the grid has room; else a power of two, 1..64 */
+  int32_t promote_after;     /* -1 default (16); mesh frames: samples after which a pixel's own ray count may promote it to
+                              * a head class (its wave then thins out around it); 0 = never */
+  int32_t cost_probe;        /* -1 default (1); mesh frames: 1 = the probe books the lane-steps of its mesh searches on the
+                              * pixels they serve and the queue's order follows that cost, 0 = it follows the ray counts */
   void *d_scratch;           /* optional device memory for ALL per-call state (work-queue cursors, ray total,
                               * completion flag, the scheduler's buffers), owned by the caller, at least */
   size_t scratch_bytes;      /* rtmi_render_scratch_bytes(frame) bytes: with it, concurrent renders of one scene
@@ -293,8 +307,9 @@ int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_o
 
 /* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
- * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PROBE_SPP environment variables override the
- * built-in defaults of those fields and are read once, when the library is first used. */
+ * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PROBE_SPP / RTMI_PLAN / RTMI_PRIO (wave_priority) /
+ * RTMI_LANE_STRIDE / RTMI_PROMOTE (promote_after) / RTMI_COST_PROBE environment variables override the built-in defaults
+ * of those fields and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);
 

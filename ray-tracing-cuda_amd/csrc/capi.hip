@@ -60,6 +60,9 @@ static RenderTuning default_tuning() {
     if (g_tune.promote < 0) g_tune.promote = 0;
     g_tune.probe_spp = env_int("RTMI_PROBE_SPP", 0);
     if (g_tune.probe_spp < 0 || g_tune.probe_spp > 64) g_tune.probe_spp = 0;
+    g_tune.cost_probe = env_int("RTMI_COST_PROBE", 1) != 0;
+    g_tune.lane_stride = env_int("RTMI_LANE_STRIDE", 0);
+    if (g_tune.lane_stride < 0 || g_tune.lane_stride > 64 || (g_tune.lane_stride & (g_tune.lane_stride - 1)) != 0) g_tune.lane_stride = 0;
     g_tune.plan = env_int("RTMI_PLAN", 1);  // list frames: planned chains instead of the queue (0 never, 1 when waves have few tiles, 2 always)
     if (g_tune.plan < 0 || g_tune.plan > 2) g_tune.plan = 1;
     g_tune.prio_every = env_int("RTMI_PRIO", 16);  // wave priorities: update interval in iterations (0: off)
@@ -78,9 +81,17 @@ static bool all_finite(const float *p, size_t n) {
   return true;
 }
 
+// (why the calling thread's last make_frame refused its frame, when the reason deserves its own words)
+static thread_local const char *t_frame_why = nullptr;
+static const char *frame_why(const char *otherwise) { return t_frame_why ? t_frame_why : otherwise; }
 static bool make_frame(const rtmi_frame *f, FrameDev *out) {
+  t_frame_why = nullptr;
+  if (f && (f->height > RTMI_MAX_EXTENT || f->width > RTMI_MAX_EXTENT)) {  // (a pixel's row and column share a word)
+    t_frame_why = "frame larger than 65535 x 65535 (RTMI_MAX_EXTENT): a pixel's row and column share a 32-bit word";
+    return false;
+  }
   if (!f || f->height <= 0 || f->width <= 0 || f->spp < 0 || f->world_size <= 0 || f->rank < 0 ||
-      f->rank >= f->world_size || f->height > 65535 || f->width > 65535)  // (a pixel's row and column share a word)
+      f->rank >= f->world_size)
     return false;
   FrameDev d;
   d.height = f->height, d.width = f->width, d.spp = f->spp, d.max_depth = f->max_depth, d.post = f->post_process;
@@ -486,7 +497,7 @@ int64_t rtmi_scene_bytes_per_ray(const rtmi_scene *sp) {
 // ------------------------------------------------------------------ frame
 int64_t rtmi_frame_work_items(const rtmi_frame *f) {
   FrameDev d;
-  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
   return d.items;
 }
 int64_t rtmi_frame_pixel_of(const rtmi_frame *f, int64_t q) {
@@ -496,7 +507,7 @@ int64_t rtmi_frame_pixel_of(const rtmi_frame *f, int64_t q) {
 }
 int rtmi_frame_pixel_map(const rtmi_frame *f, int64_t *out) {
   FrameDev d;
-  if (!make_frame(f, &d) || !out) return fail(RTMI_ERR_INVALID, "bad frame");
+  if (!make_frame(f, &d) || !out) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
   for (int64_t q = 0; q < d.items; q++) out[q] = frame_pixel_of(d, d.rank, q);
   return RTMI_OK;
 }
@@ -514,7 +525,7 @@ size_t rtmi_tiles_bytes(const rtmi_frame *f) {
 // ------------------------------------------------------------------ RNG
 int rtmi_rng_init(uint64_t seed, const rtmi_frame *f, void *d_states, void *stream) {
   FrameDev d;
-  if (!make_frame(f, &d) || !d_states) return fail(RTMI_ERR_INVALID, "bad rng_init arguments");
+  if (!make_frame(f, &d) || !d_states) return fail(RTMI_ERR_INVALID, frame_why("bad rng_init arguments"));
   if (rtmi_device_count() <= 0) return fail(RTMI_ERR_NO_DEVICE, "no HIP device: librtmi has no CPU fallback");
   uint32_t *jump = nullptr;
   int rc = device_jump(&jump);
@@ -596,7 +607,9 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
   if (opts->size != (int32_t)sizeof(rtmi_render_opts)) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.size does not match this library");
   if (opts->schedule > 2 || opts->blocks_per_cu < 0 || opts->threads_per_block < 0 || (opts->threads_per_block % 64) != 0 ||
       opts->threads_per_block > 512 || (opts->sparse_stride != 0 && !valid_stride(opts->sparse_stride)) || opts->exclusive > 1 ||
-      opts->outlier_x10 < 0 || opts->probe_spp < 0 || opts->probe_spp > 64)
+      opts->outlier_x10 < 0 || opts->probe_spp < 0 || opts->probe_spp > 64 || opts->plan > 2 || opts->wave_priority > 4096 ||
+      (opts->wave_priority > 0 && (opts->wave_priority & (opts->wave_priority - 1)) != 0) || opts->lane_stride < 0 ||
+      opts->lane_stride > 64 || (opts->lane_stride & (opts->lane_stride - 1)) != 0 || opts->cost_probe > 1)
     return fail(RTMI_ERR_INVALID, "rtmi_render_opts field out of range");
   for (int i = 0; i < 3; i++)
     if (opts->head_pct[i] < 0 || opts->head_pct[i] > 100) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.head_pct outside [0, 100]");
@@ -607,6 +620,11 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
   if (opts->exclusive >= 0) tune->exclusive = opts->exclusive;
   if (opts->outlier_x10 > 0) tune->outlier_x10 = opts->outlier_x10;
   if (opts->probe_spp > 0) tune->probe_spp = opts->probe_spp;
+  if (opts->plan >= 0) tune->plan = opts->plan;
+  if (opts->wave_priority >= 0) tune->prio_every = opts->wave_priority;
+  if (opts->lane_stride > 0) tune->lane_stride = opts->lane_stride;
+  if (opts->promote_after >= 0) tune->promote = opts->promote_after;
+  if (opts->cost_probe >= 0) tune->cost_probe = opts->cost_probe;
   for (int i = 0; i < 3; i++)
     if (opts->head_pct[i] > 0) tune->head_pct[i] = opts->head_pct[i];
   if (!(tune->head_pct[0] >= tune->head_pct[1] && tune->head_pct[1] >= tune->head_pct[2]))
@@ -618,8 +636,9 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
 // Kernel variant and launch shape of a frame on the current device.
 struct LaunchShape {
   uint32_t variant;
-  int threads, per_cu, blocks, n_cu;
+  int threads, per_cu, blocks, n_cu, lane_stride;
 };
+static constexpr int kMaxLaneStride = 16;
 static int launch_shape(const Scene *s, const FrameDev &d, const RenderTuning &tune, LaunchShape *out) {
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
@@ -651,9 +670,21 @@ static int launch_shape(const Scene *s, const FrameDev &d, const RenderTuning &t
   if (per_cu <= 0) per_cu = 1;
   int64_t want = (d.items + threads - 1) / threads;
   int64_t cap = (int64_t)n_cu * per_cu;
+  // A list frame smaller than the grid is spread thin (render_body.h: lane_stride): one pixel per 2 / 4 / ... lanes, as
+  // far as the grid has room, when the closest-hit query shares its candidate tests between the lanes of a wave (the
+  // culled list scan, the grouped sphere scan: a wave with a quarter of the rays then runs shorter iterations)
+  int stride = 1;
+  const bool shared_tests = ((variant & F_TRIS) && s->dev.n_pairs >= kCullMinPairs) || ((variant & F_SGROUP) && s->dev.n_sph_groups > 0);
+  if (!(variant & F_BVH) && shared_tests) {
+    if (tune.lane_stride > 0) stride = tune.lane_stride;
+    else
+      while (stride < kMaxLaneStride && want * stride * 2 <= cap) stride *= 2;
+  }
+  want *= stride;
   int blocks = (int)(want < cap ? want : cap);
   if (blocks < 1) blocks = 1;
   out->variant = variant, out->threads = threads, out->per_cu = per_cu, out->blocks = blocks, out->n_cu = n_cu;
+  out->lane_stride = stride;
   return RTMI_OK;
 }
 
@@ -662,7 +693,7 @@ int rtmi_render_launch_shape(const rtmi_scene *sp, const rtmi_frame *f, const rt
   const Scene *s = S(sp);
   if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
   FrameDev d;
-  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
   RenderTuning tune;
   void *scratch;
   size_t scratch_bytes;
@@ -685,12 +716,13 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   const Scene *s = S(sp);
   if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
   FrameDev d;
-  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, "bad frame");
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
   if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
   LaunchShape ls;
   if ((rc = launch_shape(s, d, tune, &ls))) return rc;
   const uint32_t variant = ls.variant;
   const int threads = ls.threads, blocks = ls.blocks;
+  tune.lane_stride = ls.lane_stride;
   hipStream_t st = (hipStream_t)stream;
   const size_t need = scratch_bytes_of(d);
   if (user_scratch && user_scratch_bytes < need)
@@ -745,8 +777,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     uint32_t *p_claims = reinterpret_cast<uint32_t *>(p_next + nt);
     int32_t *p_first = reinterpret_cast<int32_t *>(p_claims + nt);  // kMaxChains words
     // mesh frames (binary32 t): the probe also books the lane-steps of its mesh searches on the pixels they serve
-    static const bool cost_probe = env_int("RTMI_COST_PROBE", 1) != 0;
-    const bool by_cost = cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
+    const bool by_cost = tune.cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
     HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
     probe.spp = probe_spp;
@@ -781,7 +812,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     // With more the queue evens out what the probe mis-estimates better than a plan can foresee it (spheres 1024^2 x 64 spp,
     // four tiles per wave: 24.7 ms planned against 22.2 from the queue; C5's shards, eight per wave: the same either way).
     const int grid_waves = blocks * (threads / 64);
-    if (tune.plan && prio && !(variant & F_BVH) && (tune.plan == 2 || (int64_t)d.local_tiles <= 3 * (int64_t)grid_waves)) {
+    if (tune.plan && prio && !(variant & F_BVH) && ls.lane_stride == 1 && (tune.plan == 2 || (int64_t)d.local_tiles <= 3 * (int64_t)grid_waves)) {
       const int simds = ls.n_cu * 4 < grid_waves ? ls.n_cu * 4 : grid_waves;  // (four SIMDs per compute unit)
       const int rounds = (grid_waves + simds - 1) / simds;
       if (simds * rounds <= kMaxChains) {
@@ -895,7 +926,7 @@ int rccl_fail(const Rccl &R, ncclResult_t e, const char *what) {
 
 int rtmi_gather(void *nccl_comm, const rtmi_frame *f, const float *d_tiles, float *d_all_tiles, int root, void *stream) {
   FrameDev d;
-  if (!make_frame(f, &d) || !d_tiles || root < 0 || root >= d.world) return fail(RTMI_ERR_INVALID, "bad gather arguments");
+  if (!make_frame(f, &d) || !d_tiles || root < 0 || root >= d.world) return fail(RTMI_ERR_INVALID, frame_why("bad gather arguments"));
   if (d.rank == root && !d_all_tiles) return fail(RTMI_ERR_INVALID, "the root needs d_all_tiles");
   const size_t count = (size_t)d.items * 3;
   hipStream_t st = (hipStream_t)stream;
@@ -926,7 +957,7 @@ int rtmi_gather(void *nccl_comm, const rtmi_frame *f, const float *d_tiles, floa
 
 int rtmi_reduce_sum(void *nccl_comm, const rtmi_frame *f, float *d_tiles, int root, void *stream) {
   FrameDev d;
-  if (!make_frame(f, &d) || !d_tiles || root < 0) return fail(RTMI_ERR_INVALID, "bad reduce arguments");
+  if (!make_frame(f, &d) || !d_tiles || root < 0) return fail(RTMI_ERR_INVALID, frame_why("bad reduce arguments"));
   // In the reference's sample split every rank renders the WHOLE frame (utils.cu:189,216-221), so the frame says nothing
   // about how many ranks there are: the communicator does.  NULL = this rank is the only one, its sum is the sum.
   if (!nccl_comm) {
@@ -947,13 +978,13 @@ int rtmi_reduce_sum(void *nccl_comm, const rtmi_frame *f, float *d_tiles, int ro
 
 int rtmi_untile(const rtmi_frame *f, const float *d_all_tiles, float *d_image, void *stream) {
   FrameDev d;
-  if (!make_frame(f, &d) || !d_all_tiles || !d_image) return fail(RTMI_ERR_INVALID, "bad untile arguments");
+  if (!make_frame(f, &d) || !d_all_tiles || !d_image) return fail(RTMI_ERR_INVALID, frame_why("bad untile arguments"));
   HIP_TRY(launch_untile(d, d_all_tiles, d_image, (hipStream_t)stream));
   return RTMI_OK;
 }
 int rtmi_untile_u32(const rtmi_frame *f, const uint32_t *d_all, uint32_t *d_image, void *stream) {
   FrameDev d;
-  if (!make_frame(f, &d) || !d_all || !d_image) return fail(RTMI_ERR_INVALID, "bad untile arguments");
+  if (!make_frame(f, &d) || !d_all || !d_image) return fail(RTMI_ERR_INVALID, frame_why("bad untile arguments"));
   HIP_TRY(launch_untile_u32(d, d_all, d_image, (hipStream_t)stream));
   return RTMI_OK;
 }

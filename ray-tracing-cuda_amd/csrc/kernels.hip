@@ -617,6 +617,7 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.exclusive = tune.exclusive;
   lc.probe_spp = plan.probe_spp;
   lc.promote = tune.promote;
+  lc.lane_stride = tune.lane_stride > 0 ? tune.lane_stride : 1;
   lc.prio_tab = probe ? nullptr : plan.prio_tab;
   lc.tile_cost = plan.tile_cost;
   lc.rate_scale = 1.f / (64.f * (float)(plan.probe_spp > 0 ? plan.probe_spp : 1));
@@ -629,6 +630,17 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
                                              : reinterpret_cast<const void *>(render_kernel<F>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+  }
+  {  // render_body.h reads LDS by byte offset (lds_byte): right only while the kernels declare no static LDS, in EVERY
+     // build flavour (-DRTMI_STATS, -DRTMI_CHECK_MARGINS, A/B builds) -- asked of the code object once per variant
+    static const hipError_t lds_ok = [] {
+      hipFuncAttributes a{}, b{};
+      hipError_t e = hipFuncGetAttributes(&a, reinterpret_cast<const void *>(render_kernel<F>));
+      if (e == hipSuccess) e = hipFuncGetAttributes(&b, reinterpret_cast<const void *>(probe_kernel<F>));
+      if (e != hipSuccess) return e;
+      return a.sharedSizeBytes == 0 && b.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidConfiguration;
+    }();
+    if (lds_ok != hipSuccess) return lds_ok;
   }
   RenderParams rp;
   rp.sc = sc, rp.fr = fr, rp.lc = lc;

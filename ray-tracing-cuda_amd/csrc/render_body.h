@@ -33,6 +33,8 @@ struct LaunchCfg {
   const uint32_t *probe_marks;   // with head_list: bit 31 of an item's word = it is in the head
   const uint32_t *sparse_items;  // optional (with tile_order): leading work items handed to every sparse_stride-th lane only
   int32_t sparse_stride;         // power of two (RenderTuning::sparse_stride)
+  int32_t lane_stride;           // list variants, frames smaller than the grid: only every lane_stride-th lane takes pixels
+                                 // (a power of two; the others are workers of the shared candidate tests)
   int32_t prio_every;            // with prio_tab: a wave looks at its priority every this many iterations (power of two)
   uint32_t *prio_tab;            // optional: kPrioRows x 16 words, zeroed per launch -- per SIMD (row: XCC | SE | SH | CU | SIMD
                                  // of HW_ID) and wave slot (column: HW_ID.WAVE_ID), the queries the wave still has to do
@@ -267,6 +269,10 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
             const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
   uint32_t prio_tick = 0u;  // (wave-uniform)
+  // A frame with fewer pixels than the grid has lanes (C1: 65,536 on 262,144) is spread THIN: one pixel per
+  // lane_stride lanes, so that every SIMD gets a wave and a wave's shared candidate tests serve 16 rays with 64 lanes
+  // instead of 64 rays on a quarter of the SIMDs.  The idle lanes never fetch; they work in closest_hit.
+  if (!(F & F_BVH) && lc.lane_stride > 1 && (threadIdx.x & (uint32_t)(lc.lane_stride - 1)) != 0u) done = true;
   if (!(F & F_BVH) && lc.chain_next != nullptr) {  // planned chains: this wave's chain and its first tile
     const int chain = wave_chain_id(lc.prio_tab, counters + 35, lc.plan_simds, lc.plan_rounds);
     const int32_t t = chain >= 0 ? lc.chain_first[chain] : -1;

@@ -563,6 +563,40 @@ def test_thin_world_list_triangles_and_far_sphere_clouds_match_the_oracle():
         assert g[2] == o[2] and np.array_equal(g[1], o[1]) and np.array_equal(g[0], o[0], equal_nan=True), ("sphere cloud", seed)
 
 
+def test_scheduling_modes_do_not_change_a_bit():
+    """Round 4's scheduling -- wave priorities (longest remaining chain first within a SIMD), planned tile chains with
+    tile claims and take-over, thin frames (one pixel per 2..16 lanes) -- only decides which lane renders which pixel
+    when: image, per-pixel ray counts, final RNG states and the ray total are those of the plain queue, bit for bit.
+    List scenes (cornell: culled pair scan; spheres: grouped scan) and a mesh scene (priorities only)."""
+    import torch
+    import rtmi
+    cases = (("cornell_box", 256, 256, 64, 12), ("spheres", 128, 160, 64, 8), ("bunny", 96, 96, 64, 10))
+    modes = (dict(schedule=0, plan=0, wave_priority=0, lane_stride=1),  # the plain queue, image order
+             dict(schedule=2, plan=0, wave_priority=0, lane_stride=1),  # longest-first queue
+             dict(schedule=2, plan=0, wave_priority=16, lane_stride=1),  # + priorities
+             dict(schedule=2, plan=2, wave_priority=16, lane_stride=1),  # planned chains
+             dict(schedule=2, plan=2, wave_priority=1, lane_stride=1, blocks_per_cu=1),  # chains of many tiles, one workgroup per CU
+             dict(schedule=2, plan=2, wave_priority=64, lane_stride=1, probe_spp=1),
+             dict(schedule=0, plan=0, wave_priority=4, lane_stride=4),  # thin
+             dict(schedule=2, plan=2, wave_priority=16, lane_stride=16),  # thin (the plan gives way to the queue)
+             dict())  # the defaults
+    for name, h, w, spp, depth in cases:
+        b = common.build_scene(rtmi.SceneBuilder(common.scene_seed(name)), name, w / h).commit()
+        want = None
+        for kw in modes:
+            R = rtmi.Renderer(b, h, w, spp, depth, True).init_rng()
+            R.render(opts=rtmi.render_opts(**kw))
+            R.check()
+            got = (R.tiles.cpu().numpy(), R.ray_counts.cpu().numpy(), R.states.cpu().numpy(), R.total_rays())
+            if want is None:
+                want = got
+                assert got[3] > h * w * spp
+                continue
+            assert got[3] == want[3], (name, kw)
+            for x, y in zip(got[:3], want[:3]):
+                assert np.array_equal(x, y), (name, kw)
+
+
 def test_bench_shard_and_sweep_paths():
     """bench.py --shard r/G and --shard-sweep G on a small workload: the one-GPU estimate of G-GPU strong scaling (each
     shard rendered as rank r of G would render it).  The shards' ray totals add up to the full frame's."""

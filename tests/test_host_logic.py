@@ -26,7 +26,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     for name in sorted(declared):
         assert hasattr(L, name), "librtmi.so does not export %s" % name
         assert name in bound, "%s is not bound in rtmi.SYMBOLS" % name
-    assert L.rtmi_version() == 2
+    assert L.rtmi_version() == 3
 
 
 def test_float_thresholds_used_by_the_kernel():
@@ -94,6 +94,24 @@ def test_tile_shards_partition_the_frame(h, w, world):
                 assert (i - i[0] == np.repeat(np.arange(8), 8)).all() and (j - j[0] == np.tile(np.arange(8), 8)).all()
     assert (seen == 1).all()
     assert len(sizes) == 1  # every rank has the same number of work items (gather stride)
+
+
+def test_frame_extent_limit():
+    """A pixel's row and column share one 32-bit register of the trace kernel, so a frame side ends at RTMI_MAX_EXTENT =
+    65535 (the reference has no such limit; include/rtmi.h says so next to rtmi_frame) -- and the refusal says why."""
+    L = rtmi.lib()
+    hdr = open(os.path.join(ROOT, "include", "rtmi.h")).read()
+    assert "#define RTMI_MAX_EXTENT 65535" in hdr
+    ok = rtmi.make_frame(65535, 8, 1)
+    assert L.rtmi_frame_work_items(C.byref(ok)) == ((65535 + 7) // 8) * 64
+    ok = rtmi.make_frame(8, 65535, 1)
+    assert L.rtmi_frame_work_items(C.byref(ok)) == ((65535 + 7) // 8) * 64
+    for h, w in ((65536, 8), (8, 65536), (1 << 20, 1 << 20)):
+        bad = rtmi.make_frame(h, w, 1)
+        assert L.rtmi_frame_work_items(C.byref(bad)) < 0
+        assert b"65535" in L.rtmi_last_error() and b"RTMI_MAX_EXTENT" in L.rtmi_last_error()
+    bad = rtmi.make_frame(0, 8, 1)  # any other bad frame keeps the generic words
+    assert L.rtmi_frame_work_items(C.byref(bad)) < 0 and b"bad frame" in L.rtmi_last_error()
 
 
 def test_frame_validation():
@@ -264,25 +282,30 @@ def test_thin_faces_are_counted_by_what_their_nodes_must_cover():
 def test_trace_kernels_declare_no_static_lds():
     """render_body.h reads the id stack at LDS addresses formed from byte offsets of the DYNAMIC LDS array (lds_byte):
     that is only right while the array starts at LDS address 0, i.e. while no trace kernel declares static LDS
-    (group_segment_fixed_size == 0 in the code object's metadata)."""
+    (group_segment_fixed_size == 0 in the code object's metadata).  Checked on the product AND on the diagnostic
+    margin-check build (a __shared__ added under one of its macros would make the fold read wrong ids without a fault);
+    the launcher asks the same of whatever build is loaded (kernels.hip: hipFuncGetAttributes, once per variant)."""
     import subprocess
     import tempfile
     llvm = "/opt/rocm/lib/llvm/bin"
     if not os.path.exists(llvm + "/llvm-readelf"):
         pytest.skip("no llvm-readelf")
-    with tempfile.TemporaryDirectory() as tmp:
-        fat, co = os.path.join(tmp, "fatbin"), os.path.join(tmp, "co.o")
-        subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", rtmi.LIB_PATH, fat])
-        subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
-                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
-        notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co], text=True)
-    seen = 0
-    for blk in notes.split("- .agpr_count")[1:]:
-        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        if "render_kernel" in name or "probe_kernel" in name:
-            seen += 1
-            assert re.search(r"\.group_segment_fixed_size:\s+0\b", blk), name
-    assert seen >= 18
+    libs = [rtmi.LIB_PATH, os.path.join(os.path.dirname(rtmi.LIB_PATH), "librtmi_check1.so")]
+    assert os.path.exists(libs[1]), "librtmi_check1.so missing: __graft_entry__.build() builds it"
+    for lib in libs:
+        with tempfile.TemporaryDirectory() as tmp:
+            fat, co = os.path.join(tmp, "fatbin"), os.path.join(tmp, "co.o")
+            subprocess.check_call([llvm + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+            subprocess.check_call([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], stderr=subprocess.DEVNULL)
+            notes = subprocess.check_output([llvm + "/llvm-readelf", "--notes", co], text=True)
+        seen = 0
+        for blk in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+            if "render_kernel" in name or "probe_kernel" in name:
+                seen += 1
+                assert re.search(r"\.group_segment_fixed_size:\s+0\b", blk), (lib, name)
+        assert seen >= 18, lib
 
 
 def test_render_opts_validation():
@@ -297,7 +320,8 @@ def test_render_opts_validation():
     assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(bad_size), dummy, dummy, None, None) == -1
     assert b"size" in L.rtmi_last_error()
     for kw in (dict(schedule=3), dict(threads_per_block=100), dict(threads_per_block=1024), dict(sparse_stride=12),
-               dict(exclusive=2), dict(blocks_per_cu=-1), dict(probe_spp=65), dict(probe_spp=-1)):
+               dict(exclusive=2), dict(blocks_per_cu=-1), dict(probe_spp=65), dict(probe_spp=-1), dict(plan=3),
+               dict(wave_priority=12), dict(wave_priority=8192), dict(lane_stride=3), dict(lane_stride=128), dict(cost_probe=2)):
         o = rtmi.render_opts(**kw)
         assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1, kw
         assert b"out of range" in L.rtmi_last_error()
