@@ -568,8 +568,7 @@ def test_scheduling_modes_do_not_change_a_bit():
     tile claims and take-over, thin frames (one pixel per 2..16 lanes) -- only decides which lane renders which pixel
     when: image, per-pixel ray counts, final RNG states and the ray total are those of the plain queue, bit for bit.
     List scenes (cornell: culled pair scan; spheres: grouped scan) and a mesh scene (priorities only)."""
-    import torch
-    import rtmi
+    import common
     cases = (("cornell_box", 256, 256, 64, 12), ("spheres", 128, 160, 64, 8), ("bunny", 96, 96, 64, 10))
     modes = (dict(schedule=0, plan=0, wave_priority=0, lane_stride=1),  # the plain queue, image order
              dict(schedule=2, plan=0, wave_priority=0, lane_stride=1),  # longest-first queue
