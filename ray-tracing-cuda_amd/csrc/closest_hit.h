@@ -136,10 +136,10 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       // scan; a pair outside the mask cannot pass the triangle test (the bounds carry the same padding
       // and distance slack as the mesh search boxes).
       const int pair0 = run.first >> 1;
-      const float lo0 = T_FROM_F * 0.999f;
+      const float lo0 = T_FROM_F * kTimeLo;
       for (int c0 = 0; c0 < run.count; c0 += 32) {
         const int nc = run.count - c0 < 32 ? run.count - c0 : 32;
-        const float hi0 = (float)t_to * 1.0001f + 1e-6f;
+        const float hi0 = (float)t_to * kTimeHi + kTimeAbs;
         uint32_t mask = 0u;
         RTMI_STAT2(const unsigned long long tc0 = stat_now();)
         // t = (plane -+ delta - o) / d as one FMA per plane: plane * (1/d) - (o +- delta) * (1/d).  The rounding of
@@ -408,13 +408,13 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         *reinterpret_cast<int4 *>(rr) = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), __float_as_int(saf));
         *reinterpret_cast<int4 *>(rr + 4) = make_int4(__float_as_int(d.x), __float_as_int(d.y), __float_as_int(d.z), 0);
       }
-      const float sdelta = 0x1p-9f * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));  // (the groups' bounds carry 2^-9 of their own size)
+      const float sdelta = kSphDistSlack * fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));  // (the groups' bounds carry 2^-9 of their own size)
       const float six = __builtin_amdgcn_rcpf(d.x), siy = __builtin_amdgcn_rcpf(d.y), siz = __builtin_amdgcn_rcpf(d.z);
       const V3 s_inv = mk(fabsf(d.x) < 1e-30f ? copysignf(1e30f, d.x) : six, fabsf(d.y) < 1e-30f ? copysignf(1e30f, d.y) : siy,
                           fabsf(d.z) < 1e-30f ? copysignf(1e30f, d.z) : siz);
       const V3 s_klo = mk(-(o.x + sdelta) * s_inv.x, -(o.y + sdelta) * s_inv.y, -(o.z + sdelta) * s_inv.z);
       const V3 s_khi = mk(-(o.x - sdelta) * s_inv.x, -(o.y - sdelta) * s_inv.y, -(o.z - sdelta) * s_inv.z);
-      const float s_lo0 = T_FROM_F * 0.999f, s_hi0 = (float)t_to * 1.0001f + 1e-6f;
+      const float s_lo0 = T_FROM_F * kTimeLo, s_hi0 = (float)t_to * kTimeHi + kTimeAbs;
       const int member0 = __float_as_int(load_sph_group(sc.sph_groups, run.pad)[6]);  // first member of the run
       // (3) + (4): all 64 lanes, whoever's the candidates are
       auto flush = [&]() {
@@ -535,7 +535,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
                   const float bb = bf * bf;
                   const float disc_f = bb - ta4 * (oc2 - mb.w);
                   const float mag = bb + ta4 * (oc2 + mb.w);
-                  if (!(disc_f < -1e-5f * mag)) {
+                  if (!(disc_f < -kSphDiscRel * mag)) {
                     const int slot = atomicAdd(&counts[owner], 1);
                     if (slot < kSphCand) {
                       cands[owner * kSphCand + slot] = (uint16_t)(rel + i);
@@ -587,7 +587,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           const float oc2 = dot3(oc, oc), r2f = (float)r2;
           const float disc_f = bf * bf - 4.0f * saf * (oc2 - r2f);
           const float mag = bf * bf + 4.0f * saf * (oc2 + r2f);
-          if (!__any(!(disc_f < -1e-5f * mag))) continue;
+          if (!__any(!(disc_f < -kSphDiscRel * mag))) continue;
         }
         double b = (double)bf;
         float lc = len3(oc);
@@ -686,7 +686,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           const float diag = fmaxf(fmaxf(rn.mx[0] - rn.mn[0], rn.mx[1] - rn.mn[1]), rn.mx[2] - rn.mn[2]);
           const float pad = 1e-3f * diag + 1e-4f * br.mag +
                             ldexpf(0x1p-15f * (fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z)) + br.mag), br.slack_exp);
-          need = need && slab_touch(rn, pad, o, inv_d, T_FROM_F * 0.999f, (float)bt_to * 1.0001f + 1e-6f);
+          need = need && slab_touch(rn, pad, o, inv_d, T_FROM_F * kTimeLo, (float)bt_to * kTimeHi + kTimeAbs);
         }
 #endif
         // All 64 lanes walk this loop together (lanes without a ray with need == false): the search

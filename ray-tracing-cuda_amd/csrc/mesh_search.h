@@ -49,7 +49,7 @@ __device__ __forceinline__ float ubyte_f32(uint32_t x, int byte) { return (float
 // dot(tvec, pvec) / det); the padded, outward-quantised boxes cover a fixed margin, and every box is
 // widened by this fraction of (|o|_inf + largest mesh coordinate) >= |o - p0|_inf on top of it.
 #ifndef MESH_DIST_SLACK  // (a diagnostic build sets it to 0 to show what the far-face tests catch)
-#define MESH_DIST_SLACK 0x1p-16f
+#define MESH_DIST_SLACK kDistSlack
 #endif
 
 // The ray in a node's grid: per axis the time per grid step (idq) and the constants of
@@ -89,8 +89,8 @@ __device__ __forceinline__ bool child_box_hit(const NodeFrame &f, float qlx, flo
     en = fmaxf(en, fminf(tl, th));
     le = fminf(le, fmaxf(tl, th));
   }
-  const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), 1e-5f, en));
-  const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), 1e-5f, le));
+  const float lo = fmaxf(lo0, __builtin_fmaf(-fabsf(en), kSlabTimeRel, en));
+  const float hi = fminf(hi0, __builtin_fmaf(fabsf(le), kSlabTimeRel, le));
   return lo <= hi;
 }
 
@@ -189,7 +189,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, co
   const int lane = (int)(threadIdx.x & 63u);
   RTMI_STAT(st.searches++; unsigned my_steps = 0; const unsigned long long tset0 = stat_now();)
   int *stack = wl + 64 * kMeshRayWords;
-  const float lo0 = T_FROM_F * 0.999f;
+  const float lo0 = T_FROM_F * kTimeLo;
   if (need) {
     int *rr = wl + lane * kMeshRayWords;
     int w3 = 0, w7 = 0;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, co
     *reinterpret_cast<int4 *>(rr + 0) = make_int4(__float_as_int(o.x), __float_as_int(o.y), __float_as_int(o.z), w3);
     *reinterpret_cast<int4 *>(rr + 4) = make_int4(__float_as_int(d.x), __float_as_int(d.y), __float_as_int(d.z), w7);
     *reinterpret_cast<int4 *>(rr + 8) = make_int4(__float_as_int(inv_d.x), __float_as_int(inv_d.y), __float_as_int(inv_d.z),
-                                                  __float_as_int((float)bt_to * 1.0001f + 1e-6f));
+                                                  __float_as_int((float)bt_to * kTimeHi + kTimeAbs));
     *reinterpret_cast<int4 *>(rr + 12) = make_int4(0, (int)kCodeNone, (int)lo_code, 0);
   }
   const unsigned long long nm = __ballot(need);
@@ -214,7 +214,7 @@ __device__ __forceinline__ void mesh_search(const SceneDev &sc, int sub_root, co
     // table; one ray at a time is tested against all of them at once and the sub-trees it touches go
     // onto the stack.  (Boxes as conservative as the node boxes they stand for: scene.hip.)
     const BvhNode te = top[lane];
-    const float far = (float)bt_to * 1.0001f + 1e-6f;
+    const float far = (float)bt_to * kTimeHi + kTimeAbs;
     for (unsigned long long m = nm; m != 0ull; m &= m - 1ull) {
       const int rl = __builtin_ctzll(m);  // wave-uniform
       if (kMeshStackWords - sn - sf - reserve < kTopEntries) {  // no room for a whole table: start this ray at the root

@@ -92,6 +92,7 @@ struct Scene {
 
   // host-only flatten (no HIP calls); returns "" or an error message
   std::string flatten();
+  std::string check_margins() const;  // the error budget of the culls' structures, record by record (margins.h)
 };
 
 TriRec make_tri(V3 p0, V3 p1, V3 p2);

@@ -54,7 +54,7 @@ static void push_pair(Scene &s, const V3 *p, int n, int flags) {
   }
   // the padding of the mesh search boxes (padded_node_bounds): what the binary32 triangle test can accept
   // beyond the exact triangle at short range; the distance-proportional part is added at query time
-  const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
+  const float pad = fixed_pad(diag, mag);
   for (int c = 0; c < 3; c++) bx.mn[c] -= pad, bx.mx[c] += pad;
   // A thin triangle (face_slack_exponent: below 1.8 degrees) is accepted by the binary32 test from further off than the
   // scan's distance slack covers, by a factor that has no bound in the list's terms: its pair is not culled at all
@@ -187,8 +187,8 @@ static int face_slack_exponent(const V3 p[3]) {
     min_sin = std::min(min_sin, lu > 0 && lv > 0 ? cross_len / (lu * lv) : 0.0);
   }
   if (!(cross_len >= 0.9e-7)) return 0;   // |det| <= |e1 x e2| for a unit direction: never accepted (NaNs: neither)
-  if (!(min_sin < 1.0 / 32)) return 0;
-  const int k = (int)std::ceil(std::log2(1.0 / (32.0 * std::max(min_sin, 1e-12))));
+  if (!(min_sin < (double)kThinSine)) return 0;
+  const int k = (int)std::ceil(std::log2((double)kThinSine / std::max(min_sin, 1e-12)));
   return k < 0 ? 0 : k > kSlackExpMax ? kSlackExpMax : k;
 }
 
@@ -317,7 +317,7 @@ static void padded_node_bounds(const BinNode &b, float mn[3], float mx[3]) {
     diag = fmaxf(diag, b.mx[k] - b.mn[k]);
     mag = fmaxf(mag, fmaxf(fabsf(b.mn[k]), fabsf(b.mx[k])));
   }
-  const float pad = 1e-4f * diag + 1e-5f * mag + 1e-30f;
+  const float pad = fixed_pad(diag, mag);
   for (int k = 0; k < 3; k++) mn[k] = b.mn[k] - pad, mx[k] = b.mx[k] + pad;
 }
 
@@ -461,6 +461,51 @@ static void build_top_entries(const std::vector<QNode4> &qn, int sub_root, std::
     }
     tops.push_back(t);
   }
+}
+
+// ---- the error budget, record by record (margins.h).  Every structure a cull decides from is checked at commit
+// against what it stands for; a violation fails the commit (RTMI_ERR_INVALID "margin budget") instead of rendering a
+// frame that may have lost rays.
+// A search tree (local indices: children >= 0 are nodes of `qn`, < -1 face blocks of `fp`): the box a node holds for a
+// child, decoded from its 8-bit grid coordinates, must contain the fixed-padded exact bounds of every face below that
+// child, and the node's slack exponent must be at least that of every such face.
+static std::string check_search_tree(const std::vector<QNode4> &qn, const std::vector<FacePts> &fp, int node, float mn[3],
+                                     float mx[3], int *kexp) {
+  const QNode4 &nd = qn[(size_t)node];
+  for (int a = 0; a < 3; a++) mn[a] = INFINITY, mx[a] = -INFINITY;
+  *kexp = 0;
+  for (int c = 0; c < 4; c++) {
+    if (nd.child[c] == -1) continue;
+    float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int ck = 0;
+    if (nd.child[c] >= 0) {
+      const std::string e = check_search_tree(qn, fp, nd.child[c], cmn, cmx, &ck);
+      if (!e.empty()) return e;
+    } else {
+      const int enc = -(nd.child[c] + 1), cnt = enc & 7, first = enc >> 3;
+      for (int i = first; i < first + cnt; i++) {
+        ck = std::max(ck, fp[(size_t)i].kexp);
+        for (int j = 0; j < 3; j++) {
+          const float q[3] = {fp[(size_t)i].p[j].x, fp[(size_t)i].p[j].y, fp[(size_t)i].p[j].z};
+          for (int a = 0; a < 3; a++) cmn[a] = fminf(cmn[a], q[a]), cmx[a] = fmaxf(cmx[a], q[a]);
+        }
+      }
+    }
+    float diag = 0.f, mag = 0.f;
+    for (int a = 0; a < 3; a++) diag = fmaxf(diag, cmx[a] - cmn[a]), mag = fmaxf(mag, fmaxf(fabsf(cmn[a]), fabsf(cmx[a])));
+    const float pad = fixed_pad(diag, mag);
+    for (int a = 0; a < 3; a++) {
+      const double lo = (double)nd.origin[a] + std::ldexp((double)nd.qlo[a][c], nd.exp[a]);
+      const double hi = (double)nd.origin[a] + std::ldexp((double)nd.qhi[a][c], nd.exp[a]);
+      // (the pad is applied in binary32 where the bounds were built: its rounding is up to 2^-24 of the coordinate, 0.6 % of the smallest pad)
+      if (!(lo <= (double)cmn[a] - 0.98 * (double)pad && hi >= (double)cmx[a] + 0.98 * (double)pad))
+        return "margin budget: a search node's child box does not contain its faces' padded bounds";
+    }
+    if (nd.slack_exp < ck) return "margin budget: a search node's slack exponent is below a face's under it";
+    for (int a = 0; a < 3; a++) mn[a] = fminf(mn[a], cmn[a]), mx[a] = fmaxf(mx[a], cmx[a]);
+    *kexp = std::max(*kexp, ck);
+  }
+  return "";
 }
 
 // bvh.cuh:113-121: bounds; leaf if n <= kMin; else sort by positions_[0].x and
@@ -639,6 +684,12 @@ std::string Scene::flatten() {
         br.sub_root = hb.n > 0 ? build_subtree(local_sub, fp, 0, hb.n, &depth) + sub_base : -1;
         sub_depth = std::max(sub_depth, depth);
         if (depth > kSubDepthMax) return "mesh too deep for the kernel's search stack";
+        if (hb.n > 0) {  // the error budget of this mesh's search structure (margins.h)
+          float tmn[3], tmx[3];
+          int tk = 0;
+          const std::string e = check_search_tree(local_sub, fp, 0, tmn, tmx, &tk);
+          if (!e.empty()) return e;
+        }
         if ((int64_t)face_base + hb.n + 4 >= kMeshMaxFaces || (int64_t)sub_base + (int64_t)local_sub.size() >= kMeshMaxNodes)
           return "mesh too large for the kernel's 26-bit search-stack entries";
         const int node_base = (int)nodes.size();
@@ -756,7 +807,7 @@ std::string Scene::flatten() {
         m.cx = sp.cx, m.cy = sp.cy, m.cz = sp.cz, m.r2f = (float)sp.r2, m.orig = idx, m.r2 = sp.r2;
         sph_members.push_back(m);
         // the member's own box, generously: |radius| (1 + 2^-10) on every side
-        const float r = (float)(std::fabs(sp.radius) * (1.0 + 0x1p-10)) + 1e-30f;
+        const float r = (float)(std::fabs(sp.radius) * (1.0 + (double)kSphRadiusPad)) + kPadFloor;
         const float c[3] = {sp.cx, sp.cy, sp.cz};
         for (int a = 0; a < 3; a++) mn[a] = fminf(mn[a], c[a] - r), mx[a] = fmaxf(mx[a], c[a] + r);
       }
@@ -764,7 +815,7 @@ std::string Scene::flatten() {
       for (int a = 0; a < 3; a++) diag = fmaxf(diag, mx[a] - mn[a]), mag = fmaxf(mag, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
       // + the scene-dependent part of the distance slack, 2^-9 of the group's own largest coordinate (the kernel adds
       // the ray's: 2^-9 |o|): together at least 8e-4 |o - c| for every member, see closest_hit.h
-      const float pad = 1e-4f * diag + 1e-5f * mag + 0x1p-9f * mag + 1e-30f;
+      const float pad = fixed_pad(diag, mag) + kSphDistSlack * mag;
       for (int a = 0; a < 3; a++) g.mn[a] = mn[a] - pad, g.mx[a] = mx[a] + pad;
       sph_mag = fmaxf(sph_mag, mag);
       sph_groups.push_back(g);
@@ -790,7 +841,75 @@ std::string Scene::flatten() {
   if (!spheres.empty()) spheres.push_back(SphereRec{});  // same for the sphere look-ahead
   for (const MatRec &m : mat_recs)
     if (m.tex >= 0) bytes_per_ray += 4;  // one RGBA8 texel per textured hit
+  return check_margins();
+}
+
+// The error budget of the world list's structures (margins.h), record by record: a pair's bounds contain its corners
+// with the fixed pad, or are unbounded when one of its triangles is thinner than the distance slack provides for; a
+// sphere group's bounds contain every member's own box with the fixed pad and the scene's share of the distance slack;
+// a top-table entry contains the child box it stands for and carries its node's slack exponent.
+std::string Scene::check_margins() const {
+  for (size_t i = 0; i < pair_pts.size(); i++) {
+    const PairPts &pp = pair_pts[i];
+    const PairBox &bx = pair_boxes[i];
+    const bool lone = !(tris[2 * i].flags & TRI_PGRAM);
+    const V3 q[4] = {mk(pp.p0[0], pp.p0[1], pp.p0[2]), mk(pp.p1[0], pp.p1[1], pp.p1[2]), mk(pp.p2[0], pp.p2[1], pp.p2[2]),
+                     lone ? mk(pp.p2[0], pp.p2[1], pp.p2[2]) : mk(pp.p3[0], pp.p3[1], pp.p3[2])};
+    const V3 second[3] = {q[1], q[2], q[3]};
+    const bool thin = face_slack_exponent(q) > 0 || (!lone && face_slack_exponent(second) > 0);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int j = 0; j < 4; j++) {
+      const float c[3] = {q[j].x, q[j].y, q[j].z};
+      for (int a = 0; a < 3; a++) mn[a] = fminf(mn[a], c[a]), mx[a] = fmaxf(mx[a], c[a]);
+    }
+    float diag = 0.f, mag = 0.f;
+    for (int a = 0; a < 3; a++) diag = fmaxf(diag, mx[a] - mn[a]), mag = fmaxf(mag, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
+    const double pad = 0.98 * (double)fixed_pad(diag, mag);
+    for (int a = 0; a < 3; a++) {
+      if (thin ? !(bx.mn[a] == -INFINITY && bx.mx[a] == INFINITY)
+               : !((double)bx.mn[a] <= (double)mn[a] - pad && (double)bx.mx[a] >= (double)mx[a] + pad))
+        return "margin budget: a world-list pair's bounds do not cover what its triangle tests can accept";
+    }
+    if (!(mag <= list_mag)) return "margin budget: list_mag is below a pair's coordinates";
+  }
+  for (size_t g = 0; g + 1 < sph_groups.size(); g++) {  // (the last record is the look-ahead's padding)
+    const SphGroup &gr = sph_groups[g];
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < gr.count; k++) {
+      const SphMember &m = sph_members[(size_t)gr.first + k];
+      const double r = std::fabs(spheres[(size_t)m.orig].radius) * (1.0 + (double)kSphRadiusPad) * 0.999999;
+      const float c[3] = {m.cx, m.cy, m.cz};
+      for (int a = 0; a < 3; a++) mn[a] = fminf(mn[a], (float)((double)c[a] - r)), mx[a] = fmaxf(mx[a], (float)((double)c[a] + r));
+    }
+    float diag = 0.f, mag = 0.f;
+    for (int a = 0; a < 3; a++) diag = fmaxf(diag, mx[a] - mn[a]), mag = fmaxf(mag, fmaxf(fabsf(mn[a]), fabsf(mx[a])));
+    const double pad = 0.98 * ((double)fixed_pad(diag, mag) + (double)kSphDistSlack * mag);
+    for (int a = 0; a < 3; a++)
+      if (!((double)gr.mn[a] <= (double)mn[a] - pad && (double)gr.mx[a] >= (double)mx[a] + pad))
+        return "margin budget: a sphere group's bounds do not cover what its members' pre-tests can accept";
+  }
+  for (size_t b = 0; b < bvh_recs.size(); b++) {
+    for (int i = 0; i < kTopEntries; i++) {
+      const BvhNode &t = tops[b * kTopEntries + (size_t)i];
+      if (t.left == -1) continue;
+      // the entry stands for child `t.left` of some node of this mesh's search tree: find the parent's box for it
+      bool found = false;
+      for (size_t n = 0; n < qnodes.size() && !found; n++)
+        for (int c = 0; c < 4 && !found; c++)
+          if (qnodes[n].child[c] == t.left) {
+            found = true;
+            for (int a = 0; a < 3; a++) {
+              const double lo = (double)qnodes[n].origin[a] + std::ldexp((double)qnodes[n].qlo[a][c], qnodes[n].exp[a]);
+              const double hi = (double)qnodes[n].origin[a] + std::ldexp((double)qnodes[n].qhi[a][c], qnodes[n].exp[a]);
+              if (!((double)t.mn[a] <= lo && (double)t.mx[a] >= hi)) return "margin budget: a top-table entry is smaller than the child box it stands for";
+            }
+            if (t.right < qnodes[n].slack_exp) return "margin budget: a top-table entry's slack exponent is below its node's";
+          }
+      if (!found) return "margin budget: a top-table entry refers to no child of the search tree";
+    }
+  }
   return "";
 }
+
 
 }  // namespace rtmi

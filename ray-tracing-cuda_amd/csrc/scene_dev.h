@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "vec.h"
+#include "margins.h"
 
 namespace rtmi {
 

@@ -386,7 +386,7 @@ __device__ __forceinline__ bool slab_touch(const BvhNode &nd, float pad, V3 o, V
   const float t0z = (nd.mn[2] - pad - o.z) * inv_d.z, t1z = (nd.mx[2] + pad - o.z) * inv_d.z;
   const float enter = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
   const float leave = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-  lo = fmaxf(lo, enter - fabsf(enter) * 1e-5f);
-  hi = fminf(hi, leave + fabsf(leave) * 1e-5f);
+  lo = fmaxf(lo, enter - fabsf(enter) * kSlabTimeRel);
+  hi = fminf(hi, leave + fabsf(leave) * kSlabTimeRel);
   return lo <= hi;
 }
