@@ -22,11 +22,13 @@ GPU call in the parent) unless it already runs under ``python -m torch.distribut
 
 Prints ONE JSON line on rank 0, including
   roofline     — the bound the counters support: VALU issue.  ``achieved`` = issue cycles per SIMD
-                 per launch = (2 x VALU + 6 x transcendental wave-instructions per 64 rays, from the
-                 committed rocprofv3 PMC digest profiles/roofline_inputs.json) x this run's rays / 64
-                 / SIMDs; ``peak`` = the kernel's duration measured here with HIP events x 2.4 GHz.
-                 ``hbm`` keeps the SURVEY 8(d) algorithmic-bytes figure and ``traffic`` is the
-                 FETCH_SIZE+WRITE_SIZE bytes per launch of the same workload from that digest.
+                 per launch = (2 x plain + 4 x binary64 + 8 x transcendental wave-instructions per 64
+                 rays, from the committed rocprofv3 PMC digest profiles/roofline_inputs.json) x this
+                 run's rays / 64 / SIMDs; ``peak`` = the kernel's duration measured here with HIP events
+                 x 2.4 GHz.  ``counter_frac`` is the same fraction from a different counter
+                 (SQ_ACTIVE_INST_VALU x 2 / SIMDs).  ``logical_bytes`` keeps the SURVEY 8(d) bytes-per-ray
+                 figure -- scene bytes a query CONSULTS, served from SGPRs / LDS, not a memory roofline --
+                 and ``traffic`` is the FETCH_SIZE + WRITE_SIZE bytes per launch of the same workload.
   cpu_baseline — the CPU oracle ("port") on this box's cores, on SURVEY 8(d)'s two samples.
 """
 import argparse
@@ -40,7 +42,9 @@ sys.path.insert(0, os.path.join(ROOT, "ray-tracing-cuda_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 CLOCK_GHZ = 2.4        # ... max clock 2400 MHz
-CYC_VALU, CYC_TRANS = 2, 8  # issue cycles per wave-instruction on a SIMD-32 (same guide)
+# issue cycles per wave64 instruction on a SIMD (same guide): plain VALU 2, binary64 arithmetic 4 (half rate on this
+# part), transcendental 8
+CYC_VALU, CYC_F64, CYC_TRANS = 2, 4, 8
 
 WORKLOADS = {
     "c2": dict(scene="cornell_box", size=1024, spp=1024, depth=50),
@@ -198,12 +202,14 @@ def roofline(w, rays_rank, kern_ms, bytes_per_ray, n_simd, shard=None):
     scene = digest.get("kernels", {}).get(w["scene"], {})
     key = roofline_key(w, shard)
     inp = scene.get("shapes", {}).get(key)
-    hbm_alg = rays_rank * bytes_per_ray / (kern_ms * 1e-3) / 1e9
+    logical = rays_rank * bytes_per_ray / (kern_ms * 1e-3) / 1e9
     out = {"bound": "valu_issue", "achieved": None, "peak": kern_ms * 1e-3 * CLOCK_GHZ * 1e9, "unit": "cycles/SIMD",
-           "frac": None, "traffic": None,
-           "hbm": {"algorithmic_gbs": hbm_alg, "peak_gbs": HBM_PEAK_GBS, "algorithmic_frac": hbm_alg / HBM_PEAK_GBS,
-                   "note": "SURVEY 8(d) bytes/ray x rays / kernel time; these bytes are served from SGPRs / the "
-                           "scalar cache / LDS, not HBM (see traffic)"}}
+           "frac": None, "counter_frac": None, "traffic": None,
+           "logical_bytes": {"bytes_per_ray": bytes_per_ray, "gbs": logical, "over_hbm_peak": logical / HBM_PEAK_GBS,
+                             "note": "SURVEY 8(d): scene bytes a closest-hit query consults under the reference's "
+                                     "algorithm x rays / kernel time.  NOT a roofline: these bytes are served from SGPRs "
+                                     "/ the scalar cache / LDS (a ratio above 1 says exactly that); HBM sees `traffic`"},
+           "hbm": {"peak_gbs": HBM_PEAK_GBS}}
     if not inp:
         out["stale_inputs"] = "no PMC digest for %s %s in profiles/roofline_inputs.json" % (w["scene"], key)
         return out
@@ -213,10 +219,13 @@ def roofline(w, rays_rank, kern_ms, bytes_per_ray, n_simd, shard=None):
                                "re-run tools/profile_bench.sh" % (profiled, built))
         sys.stderr.write("bench.py: warning: %s\n" % out["stale_inputs"])
         return out
-    valu, trans = inp["valu_per_64_rays"], inp["trans_per_64_rays"]
-    cyc = (CYC_VALU * valu + (CYC_TRANS - CYC_VALU) * trans) * (rays_rank / 64.0) / n_simd
-    out.update(achieved=cyc, frac=cyc / out["peak"], valu_per_64_rays=valu, trans_per_64_rays=trans,
+    valu, trans, f64 = inp["valu_per_64_rays"], inp["trans_per_64_rays"], inp.get("f64_per_64_rays", 0.0)
+    cyc = (CYC_VALU * (valu - trans - f64) + CYC_F64 * f64 + CYC_TRANS * trans) * (rays_rank / 64.0) / n_simd
+    out.update(achieved=cyc, frac=cyc / out["peak"], valu_per_64_rays=valu, trans_per_64_rays=trans, f64_per_64_rays=f64,
+               cycles_per_instruction={"valu": CYC_VALU, "f64": CYC_F64, "trans": CYC_TRANS},
                clock_ghz=CLOCK_GHZ, n_simd=n_simd, source=inp.get("source"), kernel_source_hash=built)
+    if inp.get("active_valu_per_64_rays"):
+        out["counter_frac"] = inp["active_valu_per_64_rays"] * (rays_rank / 64.0) * 2.0 / n_simd / out["peak"]
     tr = inp.get("hbm_bytes_per_launch")
     if tr is not None:
         out["traffic"] = tr

@@ -52,7 +52,7 @@ inputs = {"note": "instruction mix and HBM bytes of ONE launch of render_kernel 
 for wl in wls:
     scene, key = shape_of(wl)
     pmc = {}
-    for d in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
+    for d in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
         per = {}
         for r in rows("%s_%s/**/*counter_collection.csv" % (wl, d)):
             if "render_kernel" in r["Kernel_Name"]:
@@ -74,17 +74,28 @@ for wl in wls:
         d["valu_per_64_rays"] = pmc["SQ_INSTS_VALU"] / w64
         d["trans_per_64_rays"] = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0) / w64
         d["salu_per_64_rays"] = pmc["SQ_INSTS_SALU"] / w64
+        # binary64 arithmetic issues at half the rate (4 cycles per wave-instruction against 2), transcendentals at a
+        # quarter (8): bench.CYC_*; SQ_ACTIVE_INST_VALU is the counters' own view of the same thing (cycles the VALU
+        # was busy, in units of 4 per SIMD-quad: x 2 / SIMDs = issue cycles per SIMD, as the round-3 review took it)
+        f64 = sum(pmc.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+        tr64 = pmc.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+        d["f64_per_64_rays"] = f64 / w64
+        d["trans_f64_per_64_rays"] = tr64 / w64
+        d["active_valu_per_64_rays"] = pmc.get("SQ_ACTIVE_INST_VALU", 0.0) / w64
         n_simd = 1024
         ms = pmc["_kernel_ms_pmc_sq"]
-        cyc = (2 * pmc["SQ_INSTS_VALU"] + 6 * pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)) / n_simd
+        tr = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0) + tr64
+        cyc = (bench.CYC_VALU * (pmc["SQ_INSTS_VALU"] - f64 - tr) + bench.CYC_F64 * f64 + bench.CYC_TRANS * tr) / n_simd
         d["valu_issue_frac_of_profiled_launch"] = cyc / (ms * 1e-3 * 2.4e9)
+        d["counter_frac_of_profiled_launch"] = pmc.get("SQ_ACTIVE_INST_VALU", 0.0) * 2.0 / n_simd / (ms * 1e-3 * 2.4e9)
         if "SQ_WAVE_CYCLES" in pmc and "SQ_BUSY_CYCLES" in pmc:
             d["waves"] = pmc["SQ_WAVES"]
         if "SQ_WAIT_ANY" in pmc and "SQ_ACTIVE_INST_ANY" in pmc:
             tot = pmc["SQ_WAIT_ANY"] + pmc["SQ_WAIT_INST_ANY"] + pmc["SQ_ACTIVE_INST_ANY"]
             d["wave_time_split"] = {"waiting": pmc["SQ_WAIT_ANY"] / tot, "issue_stalled": pmc["SQ_WAIT_INST_ANY"] / tot,
                                     "issuing": pmc["SQ_ACTIVE_INST_ANY"] / tot}
-        entry = {"valu_per_64_rays": d["valu_per_64_rays"], "trans_per_64_rays": d["trans_per_64_rays"],
+        entry = {"valu_per_64_rays": d["valu_per_64_rays"], "trans_per_64_rays": d["trans_per_64_rays"] + d["trans_f64_per_64_rays"],
+                 "f64_per_64_rays": d["f64_per_64_rays"], "active_valu_per_64_rays": d["active_valu_per_64_rays"],
                  "salu_per_64_rays": d["salu_per_64_rays"], "vgpr": pmc.get("_vgpr"), "sgpr": pmc.get("_sgpr"),
                  "lds_bytes": pmc.get("_lds"), "profiled_kernel_ms": ms,
                  "source": "profiles/%s_summary.json (%s)" % (tag, wl), "hbm_bytes_per_launch": None}
