@@ -738,11 +738,16 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
   SchedPlan plan;
-  // Samples per pixel of the cost probe: two.  (More do not help, not even with 1.33 pixels per lane -- a 2048^2
-  // frame over eight GPUs -- where one might expect a mis-ranked heavy tile to matter: 2 / 4 / 8 / 16 spp give 606 /
-  // 620 / 609 / 614 ms on a C4 shard.  rtmi_render_opts.probe_spp keeps it adjustable.)
+  // Samples per pixel of the cost probe: two for the queue (its order only has to be roughly longest-first: 2 / 4 / 8 /
+  // 16 spp gave 606 / 620 / 609 / 614 ms on a round-3 C4 shard).  A PLAN is only as balanced as the probe is accurate
+  // -- a tile's 2-sample estimate is 10 % off -- so a frame that will be planned spends 1 / 256 of its samples on the
+  // probe, at most 16 (C4 shard in plan mode, 2 / 8 / 16 / 32 / 64 spp: 495 / 486 / 484 / 482 / 484 ms, probe
+  // included; C2, 2 / 4 / 8: 239.6 / 237.7 / 240.2).  rtmi_render_opts.probe_spp overrides.
   const int64_t resident = (int64_t)blocks * threads;
-  const int probe_spp = tune.probe_spp > 0 ? tune.probe_spp : 2;
+  const bool may_plan = tune.plan && tune.prio_every > 0 && d.spp >= 64 && !(variant & F_BVH) && ls.lane_stride == 1 &&
+                        (tune.plan == 2 || (int64_t)d.local_tiles <= 3 * (int64_t)(blocks * (threads / 64)));
+  int probe_spp = tune.probe_spp > 0 ? tune.probe_spp : 2;
+  if (tune.probe_spp <= 0 && may_plan) probe_spp = d.spp / 256 < 2 ? 2 : d.spp / 256 > 16 ? 16 : d.spp / 256;
   const bool many_tiles = (int64_t)d.local_tiles * 64 > resident;
   const bool scheduled = tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles);
   // wave priorities (render_body.h: wave_priority_update) pay for themselves when a wave lives for many updates
@@ -812,7 +817,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     // With more the queue evens out what the probe mis-estimates better than a plan can foresee it (spheres 1024^2 x 64 spp,
     // four tiles per wave: 24.7 ms planned against 22.2 from the queue; C5's shards, eight per wave: the same either way).
     const int grid_waves = blocks * (threads / 64);
-    if (tune.plan && prio && !(variant & F_BVH) && ls.lane_stride == 1 && (tune.plan == 2 || (int64_t)d.local_tiles <= 3 * (int64_t)grid_waves)) {
+    if (may_plan && prio) {
       const int simds = ls.n_cu * 4 < grid_waves ? ls.n_cu * 4 : grid_waves;  // (four SIMDs per compute unit)
       const int rounds = (grid_waves + simds - 1) / simds;
       if (simds * rounds <= kMaxChains) {

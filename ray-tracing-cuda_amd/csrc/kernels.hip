@@ -131,7 +131,10 @@ __global__ __launch_bounds__(256) void rng_init_kernel(uint64_t seed, FrameDev f
 #endif
 // (sphere and image-texture variants: four waves, i.e. at most 128 VGPRs -- they sit just below that step, and the
 // allocator's count swings by tens of registers with unrelated edits when it is not held)
-#define RTMI_MIN_WAVES(F) (((F) & F_BVH) ? RTMI_BVH_WAVES : ((F) & (F_TEX | F_SPHERE | F_SGROUP)) ? 4 : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
+#ifndef RTMI_SPH_WAVES
+#define RTMI_SPH_WAVES 4
+#endif
+#define RTMI_MIN_WAVES(F) (((F) & F_BVH) ? RTMI_BVH_WAVES : ((F) & (F_TEX | F_SPHERE | F_SGROUP)) ? RTMI_SPH_WAVES : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
 // Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
 // workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
 #define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)

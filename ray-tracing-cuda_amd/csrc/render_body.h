@@ -68,6 +68,7 @@ __device__ __forceinline__ void wave_priority_update(uint32_t *tab, uint32_t lef
   const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);  // HW_ID, XCC_ID
   const uint32_t row = ((xcc & 15u) << 10) | (((hw >> 8) & 0xffu) << 2) | ((hw >> 4) & 3u);
   const uint32_t col = hw & 15u;  // WAVE_ID: the wave's slot on its SIMD
+  if (col >= 12u) return;         // (columns 12..15 are not wave slots: such a wave keeps the priority it has)
   uint32_t *rowp = tab + row * 16u;
   const uint32_t lane = threadIdx.x & 63u;
   uint32_t other = 0u;
@@ -76,15 +77,19 @@ __device__ __forceinline__ void wave_priority_update(uint32_t *tab, uint32_t lef
   if (lane == col) __hip_atomic_store(rowp + lane, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const bool ahead = lane < 12u && lane != col && (other > mine || (other == mine && lane < col));
   const int rank = __builtin_amdgcn_readfirstlane(__popcll(__builtin_amdgcn_ballot_w64(ahead)));
+  // level by rank: 3, 2, 1, 1, 0, 0, ... (within a level the arbiter serves the older wave first)
+#ifndef RTMI_PRIO_LEVELS
+#define RTMI_PRIO_LEVELS {3, 2, 1, 1, 0, 0, 0, 0}
+#endif
+  constexpr int levels[8] = RTMI_PRIO_LEVELS;
+  const int level = rank == 0 ? levels[0] : rank == 1 ? levels[1] : rank == 2 ? levels[2] : rank == 3 ? levels[3]
+                  : rank == 4 ? levels[4] : rank == 5 ? levels[5] : rank == 6 ? levels[6] : levels[7];
   // (s_setprio takes an immediate and ignores EXEC: one scalar branch per level)
-  if (rank == 0) __builtin_amdgcn_s_setprio(3);
-  else if (rank == 1) __builtin_amdgcn_s_setprio(2);
-  else if (rank <= 3) __builtin_amdgcn_s_setprio(1);
+  if (level == 3) __builtin_amdgcn_s_setprio(3);
+  else if (level == 2) __builtin_amdgcn_s_setprio(2);
+  else if (level == 1) __builtin_amdgcn_s_setprio(1);
   else __builtin_amdgcn_s_setprio(0);
 }
-// Planned chains: which chain is this wave's?  Column 15 of its SIMD's row counts the waves that have arrived there,
-// column 14 holds the SIMD's number + 1 once its first wave has drawn one (the others wait for it: that wave is
-// resident and a few instructions away from the store).  -1: the plan has no chain for this wave.
 __device__ __forceinline__ int wave_chain_id(uint32_t *tab, unsigned long long *simd_counter, int plan_simds, int plan_rounds) {
   const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);
   const uint32_t row = ((xcc & 15u) << 10) | (((hw >> 8) & 0xffu) << 2) | ((hw >> 4) & 3u);
@@ -106,7 +111,8 @@ __device__ __forceinline__ int wave_chain_id(uint32_t *tab, unsigned long long *
 __device__ __forceinline__ void wave_priority_leave(uint32_t *tab) {
   const uint32_t hw = __builtin_amdgcn_s_getreg(0xF804), xcc = __builtin_amdgcn_s_getreg(0xF814);
   const uint32_t row = ((xcc & 15u) << 10) | (((hw >> 8) & 0xffu) << 2) | ((hw >> 4) & 3u);
-  if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(tab + row * 16u + (hw & 15u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((threadIdx.x & 63u) == 0u && (hw & 15u) < 12u)
+    __hip_atomic_store(tab + row * 16u + (hw & 15u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <uint32_t F>
