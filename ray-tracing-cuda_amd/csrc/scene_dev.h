@@ -164,7 +164,10 @@ constexpr int kHitWords = 3;    // words per entry: code, face, t (binary32: Tri
 // [8..11] safe 1/direction, padded far bound | [12..15] hit count, cut, lo_code, claim |
 // [16..27] kHitSlots x (code, face, t).
 constexpr int kMeshRayWords = 16 + kHitSlots * kHitWords;
-constexpr int kMeshStackWords = 512;  // node entries grow up from 0, face-block entries down from the top
+#ifndef RTMI_MESH_STACK_WORDS
+#define RTMI_MESH_STACK_WORDS 512
+#endif
+constexpr int kMeshStackWords = RTMI_MESH_STACK_WORDS;  // node entries grow up from 0, face-block entries down from the top
 constexpr int kMeshWaveWords = 64 * kMeshRayWords + kMeshStackWords;
 constexpr uint32_t kCodeNone = 0xffffffffu;  // "no cut": no leaf code has bit 0 set (kRefDepthMax = 31)
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
