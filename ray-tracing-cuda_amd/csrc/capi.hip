@@ -573,8 +573,10 @@ int rtmi_rng_get_state(const rtmi_frame *f, const void *d_states, int64_t q, uin
 // ------------------------------------------------------------------ render
 // Per-call scratch: [ counters: RTMI_COUNTER_WORDS x 8 B ][ probe RNG states ][ probe ray counts ][ tile costs ]
 // [ tile order ][ 32 words of scheduler meta ][ head list: kHeadCap words ][ probe work counts ][ quarter costs ]
-// [ quarters sorted ][ quarter order ][ 4 words ].  The counters come first so that
-// rtmi_render_status can find them from the scratch pointer alone.
+// [ quarters sorted ][ quarter order ][ 4 words ][ chain plan: per tile estimate of what follows, next tile, claim; per
+// chain its first tile (kMaxChains words) ] rounded up to 256 bytes, then [ wave-priority table: kPrioTabBytes ]
+// [ two kernel-argument blocks: probe pass, real pass ].  The counters come first so that rtmi_render_status can find
+// them from the scratch pointer alone.
 static constexpr size_t kCounterBytes = RTMI_COUNTER_WORDS * sizeof(unsigned long long);
 static constexpr int kMaxChains = 1 << 15;  // planned chains: one per wave of the grid (8 waves x 4 SIMDs x 1024 CUs)
 static size_t scratch_body_bytes(const FrameDev &d);

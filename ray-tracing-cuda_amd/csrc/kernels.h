@@ -58,7 +58,6 @@ struct SchedPlan {
   uint32_t *claims = nullptr;              // one word per tile, zeroed
   int plan_simds = 0, plan_rounds = 0;
 };
-constexpr size_t kPrioTabBytes = (size_t)(1 << 14) * 16 * sizeof(uint32_t);
 // d_params: render_params_bytes() of device memory that stays untouched until the launch has finished (the kernel's
 // argument block, written in stream order just before it).
 size_t render_params_bytes();

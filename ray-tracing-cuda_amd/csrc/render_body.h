@@ -53,7 +53,6 @@ struct LaunchCfg {
   const uint32_t *tile_cost;     // optional: the probe's ray count per tile (64 pixels x probe_spp samples): a pixel's
   float rate_scale;              // rays per sample are first taken as tile_cost x rate_scale = 1 / (64 probe_spp)
 };
-constexpr int kPrioRows = 1 << 14;
 
 // Longest-remaining-chain-first between the waves of a SIMD (DESIGN "Wave priorities").  A SIMD's issue arbiter serves
 // the highest s_setprio level first and the OLDEST wave within a level: left alone, the first-dispatched wave of a

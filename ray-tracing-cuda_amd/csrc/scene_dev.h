@@ -164,10 +164,9 @@ constexpr int kHitWords = 3;    // words per entry: code, face, t (binary32: Tri
 // [8..11] safe 1/direction, padded far bound | [12..15] hit count, cut, lo_code, claim |
 // [16..27] kHitSlots x (code, face, t).
 constexpr int kMeshRayWords = 16 + kHitSlots * kHitWords;
-#ifndef RTMI_MESH_STACK_WORDS
-#define RTMI_MESH_STACK_WORDS 512
-#endif
-constexpr int kMeshStackWords = RTMI_MESH_STACK_WORDS;  // node entries grow up from 0, face-block entries down from the top
+constexpr int kMeshStackWords = 512;  // node entries grow up from 0, face-block entries down from the top
+                                      // (256 words: C3 +27 % time; larger stacks are NOT supported by the search's entry
+                                      // arithmetic -- a 768-word build faulted, NOTES.md round 4)
 constexpr int kMeshWaveWords = 64 * kMeshRayWords + kMeshStackWords;
 constexpr uint32_t kCodeNone = 0xffffffffu;  // "no cut": no leaf code has bit 0 set (kRefDepthMax = 31)
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)
@@ -210,6 +209,11 @@ struct CameraDev {
   float lens_radius;
   int32_t defocus;
 };
+
+// The wave-priority table (render_body.h: wave_priority_update): one row of 16 words per SIMD, row = XCC_ID[3:0] << 10 |
+// HW_ID[15:8] (SE, SH, CU) << 2 | HW_ID[5:4] (SIMD).
+constexpr int kPrioRows = 1 << 14;
+constexpr size_t kPrioTabBytes = (size_t)kPrioRows * 16 * sizeof(uint32_t);
 
 constexpr int kLdsMats = 512;   // at most this many material records are staged in LDS
 constexpr int kLdsNodes = 512;  // ... and this many reference-tree nodes (16 KiB)
