@@ -504,7 +504,9 @@ def main():
                 "kernel_ms_per_rank": r["per_rank_ms"], "n_ranks_seen": r["n_seen"],
                 "resident_lanes_per_rank": lanes, "pixels_per_lane": r["pixels_rank"] / float(lanes),
             },
-            "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"], shard),
+            # (N > 1: rank 0's kernel is shard 0 of N of the frame -- the digest of exactly that shard, where there is one)
+            "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"],
+                                 shard or ((rank, world) if world > 1 else None)),
         }
     if world == 1 and not args.no_extra and w["name"] == "c2" and not shard:
         # the other BASELINE configs one GPU carries, beside the headline: same contract, shorter runs.
