@@ -76,6 +76,78 @@ def test_spheres_program_against_the_oracle(tmp_path):
     assert np.array_equal(gpu, ref)
 
 
+@pytest.fixture(scope="module")
+def file_rccl(tmp_path_factory):
+    """tests/stubs/file_rccl.c: a functional stand-in for RCCL that carries messages between processes through files."""
+    out = str(tmp_path_factory.mktemp("file_rccl") / "libfile_rccl.so")
+    subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-I/opt/rocm/include", "-o", out,
+                    os.path.join(ROOT, "tests", "stubs", "file_rccl.c"), "-L/opt/rocm/lib", "-lamdhip64"], check=True)
+    return out
+
+
+def run_ranks(name, tmp_path, stub, n, h, w, spp, depth=10, extra_env=None, per_rank_setup=None):
+    """`n` processes of scene program `name` on this one GPU, their RCCL calls answered by the file-backed stub."""
+    exe = os.path.join(BIN, name)
+    if not os.path.exists(exe):
+        pytest.skip("%s not built" % exe)
+    base = tmp_path / ("%s_x%d_%s" % (name, n, "_".join(sorted((extra_env or {}).values())) or "tiles"))
+    (base / "msgs").mkdir(parents=True)
+    (base / "rdv").mkdir()
+    procs = []
+    for r in range(n):
+        d = base / ("r%d" % r)
+        d.mkdir()
+        if per_rank_setup:
+            per_rank_setup(d)
+        env = dict(os.environ, RT_HEIGHT=str(h), RT_WIDTH=str(w), RT_SPP=str(spp), RT_MAX_DEPTH=str(depth),
+                   RT_DUMP=str(d / "frame.bin"), RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT="29519",
+                   RT_RUN_ID="pytest-file-%d-%s-%d" % (os.getpid(), name, n), RT_RENDEZVOUS_DIR=str(base / "rdv"),
+                   LD_PRELOAD=stub, STUB_RCCL_DIR=str(base / "msgs"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([exe], cwd=str(d), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(l[-1500:] for l in logs)
+    assert not [f for f in os.listdir(str(base / "msgs")) if f.startswith("msg_")], "messages nobody received"
+    assert not os.path.exists(str(base / "r1" / "frame.bin"))  # only the root assembles and writes a frame
+    return np.fromfile(str(base / "r0" / "frame.bin"), dtype=np.float32).reshape(h, w, 3), logs
+
+
+def test_ranks_on_one_gpu_through_a_file_backed_rccl(tmp_path, file_rccl):
+    """DistributedMain with 2 and 3 ranks END TO END on the one GPU of the box: pixel tiles sharded by rank, every rank
+    renders its shard, `rtmi_gather` (grouped send / recv on the program's communicator, librtmi.so taking RCCL from
+    the process) brings the tile buffers to rank 0, `rtmi_untile` assembles the frame -- with the RCCL entry points
+    answered by tests/stubs/file_rccl.c, because RCCL itself refuses two ranks on one device.  The frame must be the
+    single-process frame bit for bit (utils.cu:181-242 replaced; quirk g5: pixel 0's stream is advanced by the layout's
+    draws on its owner only)."""
+    h, w, spp = 40, 56, 4
+    one, _ = run_scene("spheres", tmp_path, h, w, spp)
+    for n in (2, 3):
+        many, logs = run_ranks("spheres", tmp_path, file_rccl, n, h, w, spp)
+        assert np.array_equal(many, one), n
+        assert all("pixel-tile shard" in log for log in logs)
+    # a mesh scene: every rank loads the model and builds the same trees
+    h, w, spp = 32, 32, 2
+    one, _ = (assets(tmp_path), run_scene("bunny", tmp_path, h, w, spp))[1]
+    many, _ = run_ranks("bunny", tmp_path, file_rccl, 2, h, w, spp, per_rank_setup=assets)
+    assert np.array_equal(many, one)
+
+
+def test_reference_sample_split_on_two_ranks(tmp_path, file_rccl):
+    """RT_DIST_MODE=spp: the reference's own decomposition (utils.cu:111-130,189,220,238) -- every rank renders the WHOLE
+    frame with GetWorkload(rank, world, spp) samples from the SAME seed (quirk g11: rank 1's samples are a prefix of rank
+    0's), no post-process; `rtmi_reduce_sum` adds the frames on rank 0, which divides by the total and post-processes.
+    Expected: the oracle's two raw frames added and post-processed the same way."""
+    import rtmi
+    h, w, spp = 32, 40, 5
+    got, logs = run_ranks("spheres", tmp_path, file_rccl, 2, h, w, spp, extra_env={"RT_DIST_MODE": "spp"})
+    assert all("sample split" in log for log in logs)
+    parts = [common.oracle_render("spheres", h, w, rtmi.get_workload(r, 2, spp), 10, post=False)[0] for r in range(2)]
+    assert [rtmi.get_workload(r, 2, spp) for r in range(2)] == [3, 2]
+    want = np.sqrt(np.clip((parts[0] + parts[1]) / np.float32(spp), np.float32(0), np.float32(1))).astype(np.float32)
+    assert common.rel_l2(got, want) <= 1e-3
+    assert (got == want).all(axis=2).mean() > 0.98
+
+
 def write_ppm(path, rgb):
     """Binary PPM (P6): the stb_image stand-in (api/compat/stb_image.h) decodes it losslessly, whatever the file is
     called, so the texels the scene program samples are exactly the array the oracle is given."""
