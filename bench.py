@@ -255,6 +255,9 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
     opts = rtmi.render_opts(probe_spp=args.probe_spp) if args.probe_spp > 0 else None
     shape = R.launch_shape(opts)
     torch.cuda.synchronize()
+    # (the exchange's tensors stay on the device with RCCL; the gloo test hook of main() takes them through the host)
+    on_device = not (use_dist and dist.get_backend() == "gloo")
+    xdev = "cuda" if on_device else "cpu"
 
     def step(ev=None):
         R.states.copy_(pristine)
@@ -267,9 +270,9 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
             R.check()  # one shard of G: there is no frame to assemble on this GPU
         elif use_dist:
             R.check()  # an incomplete frame raises here, before it is handed on
-            allt = gather_to_root(R.tiles, 0)
+            allt = gather_to_root(R.tiles if on_device else R.tiles.cpu(), 0)
             if rank == 0:
-                R.untile(allt)
+                R.untile(allt if on_device else allt.cuda())
         else:
             R.untile()
 
@@ -294,12 +297,12 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
     rays_all = float(rays_rank)
     n_seen = 1
     if use_dist and not shard:
-        tt = torch.tensor([dt, float(rays_rank), kern_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt, float(rays_rank), kern_ms], dtype=torch.float64, device=xdev)
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = tt.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        allk = [torch.zeros(1, dtype=torch.float64, device="cuda") for _ in range(world)]
+        allk = [torch.zeros(1, dtype=torch.float64, device=xdev) for _ in range(world)]
         dist.all_gather(allk, tt[2:3].clone())
         dt, rays_all = float(tmax[0]), float(tsum[1])
         per_rank_ms = [float(x[0]) for x in allk]
@@ -462,11 +465,19 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus %d: refusing to run a different number of ranks" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    # TEST HOOK (tests/test_gpu_round3.py): RTMI_BENCH_TEST_ONE_GPU=1 runs every rank on cuda:0 and the exchange over
+    # gloo, so that the N-rank code of this file runs with real rendering on a one-GPU box (RCCL refuses two ranks on
+    # one device).  Its line is marked "test_one_gpu": it is not a measurement.
+    one_gpu_test = os.environ.get("RTMI_BENCH_TEST_ONE_GPU") == "1"
+    if one_gpu_test:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit("rank %d needs GPU %d but only %d visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = launch.under_launcher()  # under torch.distributed.run even with one rank
-    if use_dist:
+    if use_dist and one_gpu_test:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.blocks_per_cu or args.threads:
         rtmi.lib().rtmi_set_launch(args.blocks_per_cu, args.threads)
@@ -493,6 +504,8 @@ def main():
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": r["dt"] / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            **({"test_one_gpu": "all ranks on cuda:0, exchange over gloo: a functional test, not a measurement"}
+               if os.environ.get("RTMI_BENCH_TEST_ONE_GPU") == "1" else {}),
             "config": {
                 "workload": "%s: scenes/%s %dx%d x%dspp depth%d seed%d (fixed frame; 8x8 tiles interleaved over %d "
                             "rank(s)%s; step = trace kernel%s)" %

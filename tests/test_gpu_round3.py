@@ -617,6 +617,36 @@ def test_bench_shard_and_sweep_paths():
     assert line["n_gpus"] == 1 and "shard 1 only" in line["config"]["workload"] and line["value"] > 0
 
 
+def test_bench_n_rank_code_with_real_rendering_on_one_gpu():
+    """bench.py --gpus 2 and 3 with its one-GPU test hook (every rank on cuda:0, exchange over gloo): the N-rank code of
+    the bench -- per-rank shards, barrier-bracketed timing, max over ranks, the gather of the tile buffers, untile on rank
+    0, the per-rank kernel times -- with real rendering.  The ray total of the ranks' shards is the single-rank frame's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+
+    def run(n, extra=None):
+        e = dict(env, **(extra or {}))
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--workload", "c1", "--steps", "2",
+                            "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--rank-timeout", "300"],
+                           capture_output=True, text=True, timeout=600, env=e)
+        assert r.returncode == 0, r.stdout + r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        return json.loads(lines[0])
+
+    one = run(1)
+    for n in (2, 3):
+        d = run(n, {"RTMI_BENCH_TEST_ONE_GPU": "1"})
+        assert d["n_gpus"] == n and d["config"]["n_ranks_seen"] == n and len(d["config"]["kernel_ms_per_rank"]) == n
+        assert "test_one_gpu" in d and d["scaling"] == "strong"
+        assert d["config"]["rays_per_step"] == one["config"]["rays_per_step"]
+        assert d["value"] > 0 and d["ms_per_step"] > 0 and "RCCL gather" in d["config"]["workload"]
+
+
 def test_everything_at_once_variant():
     """A world that needs every kernel feature together (the F_ALL specialisation): a grouped sphere run, world-list
     pairs, two meshes (one with texture coordinates under an image texture), a defocus camera."""
