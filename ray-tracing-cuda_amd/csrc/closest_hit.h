@@ -232,7 +232,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           // a test that passed against the older, larger t_to passes now iff its t <= the current one,
           // which is the only place t_to enters the test (utils.cu:74).
           constexpr int RW = (F & F_TEX) ? 6 : 2;  // result words per task: t of the two triangles (+ their u, v)
-          int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks;
+          int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks(F);
           const int cnt = __builtin_popcount(mask);
           const int base = wave_prefix_excl(cnt);
           if (cnt != 0) {
@@ -251,7 +251,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
             RTMI_STAT(st.cull_iters++;)
             const int lo_t = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
-            const bool now = todo && base + cnt - lo_t <= kListTasks;
+            const bool now = todo && base + cnt - lo_t <= kListTasks(F);
             const int n_now = __builtin_amdgcn_readlane(base + cnt, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo_t;
             if (now) {  // (a)
               int k = base - lo_t;
@@ -398,7 +398,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
       // its wave through the plain loop for this run instead.
       const int n_groups = (run.count + kSphGroupSize - 1) / kSphGroupSize;
       uint16_t *my_cands = cands + lane * kSphCand;
-      int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks;
+      int *tasks = ll + 64 * 8, *results = ll + 64 * 8 + kListTasks(F);
       int ccnt = 0;  // candidates of this lane's ray
       bool have = false;
       double best_v = 0.0;
@@ -423,7 +423,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         bool todo = cnt != 0;
         while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
           const int lo_t = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
-          const bool now = todo && base + cnt - lo_t <= kListTasks;
+          const bool now = todo && base + cnt - lo_t <= kListTasks(F);
           const int n_now = __builtin_amdgcn_readlane(base + cnt, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo_t;
           if (now)
             for (int j = 0; j < cnt; j++) tasks[base - lo_t + j] = (lane << 16) | (int)my_cands[j];
@@ -504,7 +504,7 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
         bool todo = cnt != 0;
         while (__builtin_amdgcn_ballot_w64(todo) != 0ull) {
           const int lo_t = __builtin_amdgcn_readlane(base, __builtin_ctzll(__builtin_amdgcn_ballot_w64(todo)));
-          const bool now = todo && base + cnt - lo_t <= kListTasks;
+          const bool now = todo && base + cnt - lo_t <= kListTasks(F);
           const int n_now = __builtin_amdgcn_readlane(base + cnt, 63 - __builtin_clzll(__builtin_amdgcn_ballot_w64(now))) - lo_t;
           if (now) {
             int k = base - lo_t;

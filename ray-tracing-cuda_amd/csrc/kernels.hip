@@ -129,12 +129,16 @@ __global__ __launch_bounds__(256) void rng_init_kernel(uint64_t seed, FrameDev f
 #ifndef RTMI_BVH_WAVES
 #define RTMI_BVH_WAVES 3
 #endif
-// (sphere and image-texture variants: four waves, i.e. at most 128 VGPRs -- they sit just below that step, and the
-// allocator's count swings by tens of registers with unrelated edits when it is not held)
+// Sphere and image-texture variants: four waves (at most 128 VGPRs: they sit just below that step, and the allocator's
+// count swings by tens of registers with unrelated edits when it is not held) -- except the three that gain from a
+// fifth (96 VGPRs, 6-21 spilled dwords) now that their task regions leave room for a fifth workgroup in a CU's LDS
+// (scene_dev.h: kListTasks): triangles + spheres + textures (C5 shard 3.16 -> 2.93 s), the grouped sphere scan (spheres
+// 1024^2: 22.2 -> 20.9 ms), short sphere runs (+2 %).  Spheres + triangles without textures lose 4-5 % at five (spills
+// with no occupancy to show for them) and stay at four.  (tools/gpu_variant_time.py for the variants no workload uses)
 #ifndef RTMI_SPH_WAVES
-#define RTMI_SPH_WAVES 4
+#define RTMI_SPH_WAVES(F) (((F) == (F_TRIS | F_SPHERE | F_TEX) || (F) == (F_SPHERE | F_SGROUP) || (F) == F_SPHERE) ? 5 : 4)
 #endif
-#define RTMI_MIN_WAVES(F) (((F) & F_BVH) ? RTMI_BVH_WAVES : ((F) & (F_TEX | F_SPHERE | F_SGROUP)) ? RTMI_SPH_WAVES : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
+#define RTMI_MIN_WAVES(F) (((F) & F_BVH) ? RTMI_BVH_WAVES : ((F) & (F_TEX | F_SPHERE | F_SGROUP)) ? RTMI_SPH_WAVES(F) : ((F) & F_TRIS) ? RTMI_TRIS_WAVES : 6)
 // Mesh variants share their per-workgroup tables (reference-tree nodes, materials) between more waves:
 // workgroups of up to 512 lanes, two of which fill a CU's LDS with 16 waves' search regions.
 #define RTMI_MAX_THREADS(F) (((F) & F_BVH) ? 512 : 256)

@@ -99,11 +99,16 @@ struct alignas(16) TriNrm {
   int32_t mat_flags;
 };
 constexpr int kCullMinPairs = 4;  // shorter lists are scanned plainly: the cull and the hand-over through LDS cost more than they save
-constexpr int kListTasks = 192;  // (ray, pair) tasks of the culled list scan that one wave holds in LDS at a time
-// words of one wave's region for shared candidate tests: 64 ray records of 8 words, kListTasks tasks, and per task
+// (ray, pair) / (ray, group) / (ray, sphere) tasks of the shared candidate tests that one wave holds in LDS at a time.
+// The capacity decides how many workgroups a CU's LDS holds, so it is per variant: the plain list kernel (six waves per
+// SIMD, 25 KiB per workgroup at depth 50) keeps 192 (96: C2 +2.5 % time, more flush rounds); with image textures a task
+// carries six result words and 192 of them held the variant at four workgroups per CU -- with 96 a fifth fits (C5 shard
+// 3.16 -> 2.93 s together with the 96-VGPR build); the grouped sphere scan: 128 (spheres 1024^2: 22.2 -> 20.9 ms).
+constexpr int kListTasks(uint32_t features) { return (features & 16u) ? 96 : (features & 4u) ? 128 : 192; }  // (16 = F_TEX, 4 = F_SGROUP)
+// words of one wave's region for shared candidate tests: 64 ray records of 8 words, the tasks, and per task
 // the results -- t of a pair's two triangles (+ their u, v with image textures), or a sphere's v (binary64) and index
 constexpr int kListWaveWords(uint32_t features) {
-  return 64 * 8 + kListTasks * (1 + ((features & 16u) ? 6 : (features & 1u) ? 3 : 2));  // (16 = F_TEX, 1 = F_SPHERE)
+  return 64 * 8 + kListTasks(features) * (1 + ((features & 16u) ? 6 : (features & 1u) ? 3 : 2));  // (16 = F_TEX, 1 = F_SPHERE)
 }
 constexpr int kLdsPairs = 128;  // at most this many PairPts records are staged in LDS (8 KiB); longer lists use the plain scan
 
