@@ -271,7 +271,7 @@ typedef struct rtmi_render_opts {
                               * they render too */
   int32_t outlier_x10;       /* 0 default (20); with sparse_stride > 0: a tile is an outlier from this many tenths of
                               * the mean tile cost */
-  int32_t probe_spp;         /* 0 default (2): samples per pixel of the scheduler's cost probe, 1..64 */
+  int32_t probe_spp;         /* 0 default: samples per pixel of the scheduler's first look at the frame (see first_pass), 1..64 */
   int32_t head_pct[3];       /* 0 default (80, 55, 30): mesh frames, per cent of the frame's largest probe count from
                               * which a pixel gets a wave to itself / shares one with another / gets one lane in 16 */
   int32_t plan;              /* -1 default (1).  List scenes (no mesh) with a probe behind the launch: 0 = every lane takes its
@@ -288,6 +288,12 @@ typedef struct rtmi_render_opts {
                               * a head class (its wave then thins out around it); 0 = never */
   int32_t cost_probe;        /* -1 default (1); mesh frames: 1 = the probe books the lane-steps of its mesh searches on the
                               * pixels they serve and the queue's order follows that cost, 0 = it follows the ray counts */
+  int32_t first_pass;        /* -1 default (1).  1 = the scheduler's probe is the frame's OWN first samples: samples [0, s1) of
+                              * every pixel go into the caller's buffers, their ray counts order / plan the rest, a second
+                              * launch resumes every pixel at sample s1 (s1 = probe_spp, or by default spp / 16, at most 64,
+                              * for a frame that will be planned, else 2); N > 1 = the same with spp / N; 0 = probe_spp
+                              * samples on a scratch copy of the RNG states, discarded */
+  int32_t reserved;
   void *d_scratch;           /* optional device memory for ALL per-call state (work-queue cursors, ray total,
                               * completion flag, the scheduler's buffers), owned by the caller, at least */
   size_t scratch_bytes;      /* rtmi_render_scratch_bytes(frame) bytes: with it, concurrent renders of one scene
@@ -308,7 +314,7 @@ int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_o
 /* Process-wide DEFAULTS for the same fields (what rtmi_render and a zero field of rtmi_render_opts use).
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
  * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PROBE_SPP / RTMI_PLAN / RTMI_PRIO (wave_priority) /
- * RTMI_LANE_STRIDE / RTMI_PROMOTE (promote_after) / RTMI_COST_PROBE environment variables override the built-in defaults
+ * RTMI_LANE_STRIDE / RTMI_PROMOTE (promote_after) / RTMI_COST_PROBE / RTMI_FIRST_PASS environment variables override the built-in defaults
  * of those fields and are read once, when the library is first used. */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);

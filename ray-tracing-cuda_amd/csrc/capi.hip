@@ -61,6 +61,8 @@ static RenderTuning default_tuning() {
     g_tune.probe_spp = env_int("RTMI_PROBE_SPP", 0);
     if (g_tune.probe_spp < 0 || g_tune.probe_spp > 64) g_tune.probe_spp = 0;
     g_tune.cost_probe = env_int("RTMI_COST_PROBE", 1) != 0;
+    g_tune.first_pass = env_int("RTMI_FIRST_PASS", 1);  // 0: a discarded probe; 1: the frame's first spp / 16 samples; N > 1: spp / N
+    if (g_tune.first_pass < 0) g_tune.first_pass = 1;
     g_tune.lane_stride = env_int("RTMI_LANE_STRIDE", 0);
     if (g_tune.lane_stride < 0 || g_tune.lane_stride > 64 || (g_tune.lane_stride & (g_tune.lane_stride - 1)) != 0) g_tune.lane_stride = 0;
     g_tune.plan = env_int("RTMI_PLAN", 1);  // list frames: planned chains instead of the queue (0 never, 1 when waves have few tiles, 2 always)
@@ -95,6 +97,7 @@ static bool make_frame(const rtmi_frame *f, FrameDev *out) {
     return false;
   FrameDev d;
   d.height = f->height, d.width = f->width, d.spp = f->spp, d.max_depth = f->max_depth, d.post = f->post_process;
+  d.k_begin = 0, d.k_end = f->spp;
   d.rank = f->rank, d.world = f->world_size;
   d.tiles_x = (f->width + RTMI_TILE - 1) / RTMI_TILE;
   d.tiles_y = (f->height + RTMI_TILE - 1) / RTMI_TILE;
@@ -611,7 +614,7 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
       opts->threads_per_block > 512 || (opts->sparse_stride != 0 && !valid_stride(opts->sparse_stride)) || opts->exclusive > 1 ||
       opts->outlier_x10 < 0 || opts->probe_spp < 0 || opts->probe_spp > 64 || opts->plan > 2 || opts->wave_priority > 4096 ||
       (opts->wave_priority > 0 && (opts->wave_priority & (opts->wave_priority - 1)) != 0) || opts->lane_stride < 0 ||
-      opts->lane_stride > 64 || (opts->lane_stride & (opts->lane_stride - 1)) != 0 || opts->cost_probe > 1)
+      opts->lane_stride > 64 || (opts->lane_stride & (opts->lane_stride - 1)) != 0 || opts->cost_probe > 1 || opts->first_pass > 4096)
     return fail(RTMI_ERR_INVALID, "rtmi_render_opts field out of range");
   for (int i = 0; i < 3; i++)
     if (opts->head_pct[i] < 0 || opts->head_pct[i] > 100) return fail(RTMI_ERR_INVALID, "rtmi_render_opts.head_pct outside [0, 100]");
@@ -627,6 +630,7 @@ static int resolve_opts(const rtmi_render_opts *opts, RenderTuning *tune, void *
   if (opts->lane_stride > 0) tune->lane_stride = opts->lane_stride;
   if (opts->promote_after >= 0) tune->promote = opts->promote_after;
   if (opts->cost_probe >= 0) tune->cost_probe = opts->cost_probe;
+  if (opts->first_pass >= 0) tune->first_pass = opts->first_pass;
   for (int i = 0; i < 3; i++)
     if (opts->head_pct[i] > 0) tune->head_pct[i] = opts->head_pct[i];
   if (!(tune->head_pct[0] >= tune->head_pct[1] && tune->head_pct[1] >= tune->head_pct[2]))
@@ -740,18 +744,40 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
   // tile is long enough for the 2-spp probe to be cheap.
   SchedPlan plan;
-  // Samples per pixel of the cost probe: two for the queue (its order only has to be roughly longest-first: 2 / 4 / 8 /
-  // 16 spp gave 606 / 620 / 609 / 614 ms on a round-3 C4 shard).  A PLAN is only as balanced as the probe is accurate
-  // -- a tile's 2-sample estimate is 10 % off -- so a frame that will be planned spends 1 / 256 of its samples on the
-  // probe, at most 16 (C4 shard in plan mode, 2 / 8 / 16 / 32 / 64 spp: 495 / 486 / 484 / 482 / 484 ms, probe
-  // included; C2, 2 / 4 / 8: 239.6 / 237.7 / 240.2).  rtmi_render_opts.probe_spp overrides.
   const int64_t resident = (int64_t)blocks * threads;
+  // When is a list frame planned?  The plan wins where the queue cannot even things out (few tiles per wave) AND its
+  // estimates are good enough (long pixels: many samples).  Measured, planned against queued, cornell depth 50: 1.33
+  // tiles per wave (a 2048^2 frame over eight GPUs): 128 spp 20.9 / 21.0 ms, 512 spp 66 / 77, 4096 spp 480 / 590; 2.67
+  // tiles per wave (1024^2): 128 spp 38.3 / 35.1, 256 spp 66.8 / 64.3, 512 spp 122.4 / 123.5, 1024 spp 237 / 241; 5.3
+  // (half a 2048^2 x 4096 frame) 1763 / 1787; 6.4 (a C5 shard, 8192 spp) 2853 / 2917; 10.7: the same.  Spheres 1024^2 x
+  // 64 spp, 3.2 tiles per wave: 21.3-22.6 / 20.4.
+  const int64_t plan_tiles = d.local_tiles, plan_waves = (int64_t)blocks * (threads / 64);
+  const bool plan_pays = (2 * plan_tiles <= 3 * plan_waves && d.spp >= 128) || (plan_tiles <= 3 * plan_waves && d.spp >= 512) ||
+                         (plan_tiles <= 8 * plan_waves && d.spp >= 2048);
   const bool may_plan = tune.plan && tune.prio_every > 0 && d.spp >= 64 && !(variant & F_BVH) && ls.lane_stride == 1 &&
-                        (tune.plan == 2 || (int64_t)d.local_tiles <= 3 * (int64_t)(blocks * (threads / 64)));
+                        (tune.plan == 2 || plan_pays);
+  // Samples of the scheduler's first look at the frame.  As a DISCARDED probe (first_pass = 0): two for the queue (its
+  // order only has to be roughly longest-first: 2 / 4 / 8 / 16 spp gave 606 / 620 / 609 / 614 ms on a round-3 C4 shard),
+  // 1 / 256 of the frame's samples, at most 16, for a plan, which is only as balanced as its estimates (C4 shard 2 / 8 /
+  // 16 / 32 / 64: 495 / 486 / 484 / 482 / 484 ms, probe included).  rtmi_render_opts.probe_spp overrides either way.
   int probe_spp = tune.probe_spp > 0 ? tune.probe_spp : 2;
   if (tune.probe_spp <= 0 && may_plan) probe_spp = d.spp / 256 < 2 ? 2 : d.spp / 256 > 16 ? 16 : d.spp / 256;
   const bool many_tiles = (int64_t)d.local_tiles * 64 > resident;
-  const bool scheduled = tune.schedule == 2 || (tune.schedule == 1 && d.spp >= 32 * probe_spp && many_tiles);
+  // The probe is the frame's own first samples (tune.first_pass): samples [0, s1) of every pixel are rendered into the
+  // caller's buffers from the queue in image order, their ray counts order / plan the rest, and the second launch
+  // resumes every pixel at sample s1 -- nothing is rendered twice, and s1 can be a sixteenth of the frame where a
+  // discarded probe had to stay at a few samples (a 64-spp frame planned on 2 discarded samples: 21.9 ms; on 8: 20.5,
+  // their cost included).  first_pass = 0 keeps the discarded probe on a scratch copy of the RNG states.
+  const bool two_pass = tune.first_pass != 0;
+  if (two_pass && tune.probe_spp <= 0) {
+    // a frame that will be planned spends a sixteenth of its samples (at most 64) on the first pass: the plan is as good
+    // as its estimates (C2: 238.9 -> 236.9 ms); everything else two -- the first pass runs from the plain queue, which
+    // is the slower way to render a mesh frame (C3 with 32 first samples: 83 ms against 74) or a short one (spheres
+    // 1024^2 x 64 spp: 2 / 4 / 8 first samples 20.3 / 20.7 / 21.5 ms; the discarded 2-spp probe: 20.9)
+    const int div = tune.first_pass > 1 ? tune.first_pass : 16;
+    probe_spp = !may_plan ? 2 : d.spp / div < 2 ? 2 : d.spp / div > 64 ? 64 : d.spp / div;
+  }
+  const bool scheduled = tune.schedule == 2 || (tune.schedule == 1 && many_tiles && (two_pass ? d.spp >= 32 && d.spp >= 2 * probe_spp : d.spp >= 32 * probe_spp));
   // wave priorities (render_body.h: wave_priority_update) pay for themselves when a wave lives for many updates
   const bool prio = tune.prio_every > 0 && d.spp >= 64;
   void *scratch = user_scratch;
@@ -766,6 +792,8 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     }
     scratch = ms->d_sched;
   }
+  FrameDev first = d;               // the launch that finishes the frame: all of it, or what a first pass left
+  uint32_t *ray_buf = d_ray_counts;  // (a resumed pixel reads its count back: scratch when the caller wants none)
   if (prio) {
     plan.prio_tab = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(scratch) + scratch_body_bytes(d));
     HIP_TRY(hipMemsetAsync(plan.prio_tab, 0, kPrioTabBytes, st));
@@ -785,18 +813,34 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     int32_t *p_first = reinterpret_cast<int32_t *>(p_claims + nt);  // kMaxChains words
     // mesh frames (binary32 t): the probe also books the lane-steps of its mesh searches on the pixels they serve
     const bool by_cost = tune.cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
-    HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
+    // first pass: the frame's own samples [0, probe_spp) into the caller's buffers, or a discarded probe on copies
+    const bool resume = two_pass && probe_spp < d.spp;
+    uint32_t *first_states = resume ? reinterpret_cast<uint32_t *>(d_states) : p_states;
+    uint32_t *first_rays = resume && d_ray_counts ? d_ray_counts : p_rays;
+    if (!resume) HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));
     FrameDev probe = d;
-    probe.spp = probe_spp;
+    if (resume) {
+      probe.k_end = probe_spp;
+      first.k_begin = probe_spp, ray_buf = first_rays;
+    } else {
+      probe.spp = probe_spp, probe.k_end = probe_spp;
+    }
     HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
-    // the probe writes its (discarded) radiance into d_tiles, which the real pass overwrites
+    // (a discarded probe writes its radiance into d_tiles, which the real pass overwrites)
     SchedPlan probe_plan;
     if (by_cost) {
       HIP_TRY(hipMemsetAsync(p_work, 0, n * 4, st));
       probe_plan.visit_counts = p_work;
     }
-    HIP_TRY(launch_render(variant, s->dev, probe, p_states, d_tiles, p_rays, counters, probe_plan, true, blocks,
+    HIP_TRY(launch_render(variant, s->dev, probe, first_states, d_tiles, first_rays, counters, probe_plan, true, blocks,
                           threads, tune, params, st));
+    if (resume) {
+      // The scheduler's kernels read the first pass's ray counts and MARK the head's pixels in them (bit 31), and the
+      // marks must outlive the pixels' final counts, which the second launch writes into the same words as it goes: they
+      // work on a copy (in the region a discarded probe's RNG states would have used).
+      HIP_TRY(hipMemcpyAsync(p_states, first_rays, n * 4, hipMemcpyDeviceToDevice, st));
+      p_rays = p_states;
+    }
     const uint32_t sparse_cap = (uint32_t)(((int64_t)blocks * threads / tune.sparse_stride) / 64 * 64);
     // the head of a mesh frame's queue: pixels in weight classes (the default), or -- when the call names a
     // sparse stride, or RTMI_HEAD_CLASSES=0 -- the outlier tiles at one pixel per that many lanes
@@ -815,9 +859,6 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     plan.probe_spp = probe_spp;
     plan.tile_cost = p_cost;
     // list frames: planned chains instead of the queue (kernels.h: launch_chain_plan)
-    // -- when a wave has few tiles to render (at most three on average: a 2048^2 frame over eight GPUs has 1.33, C2 2.67).
-    // With more the queue evens out what the probe mis-estimates better than a plan can foresee it (spheres 1024^2 x 64 spp,
-    // four tiles per wave: 24.7 ms planned against 22.2 from the queue; C5's shards, eight per wave: the same either way).
     const int grid_waves = blocks * (threads / 64);
     if (may_plan && prio) {
       const int simds = ls.n_cu * 4 < grid_waves ? ls.n_cu * 4 : grid_waves;  // (four SIMDs per compute unit)
@@ -832,7 +873,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     }
   }
   HIP_TRY(hipMemsetAsync(counters, 0, kCounterBytes, st));
-  HIP_TRY(launch_render(variant, s->dev, d, reinterpret_cast<uint32_t *>(d_states), d_tiles, d_ray_counts, counters,
+  HIP_TRY(launch_render(variant, s->dev, first, reinterpret_cast<uint32_t *>(d_states), d_tiles, ray_buf, counters,
                         plan, false, blocks, threads, tune, params + render_params_bytes(), st));
   return RTMI_OK;
 }

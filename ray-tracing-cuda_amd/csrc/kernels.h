@@ -34,6 +34,8 @@ struct RenderTuning {
                       // shares one with another, gets one lane in 16 (80 / 55 / 30)
   int probe_spp;      // samples per pixel of the scheduler's cost probe; 0: chosen per frame (capi.hip)
   int promote;        // samples after which a mesh frame's pixel may be promoted to a head class by its own ray count; 0: never
+  int first_pass;     // 0: the scheduler's probe is rendered on scratch copies and discarded; 1: it is the frame's own first spp / 16
+                      // samples (the second launch resumes); N > 1: spp / N
   int cost_probe;     // mesh frames: 1 = the probe books its searches' lane-steps per pixel and the queue follows that cost
   int lane_stride;    // list frames smaller than the grid: one pixel per this many lanes (power of two; 0: chosen per frame)
   int plan;           // 1: list frames with a probe behind them are rendered as planned chains (launch_chain_plan), not from the queue

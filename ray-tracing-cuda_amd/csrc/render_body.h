@@ -257,10 +257,14 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
     rng.v2 = states[3 * n_items + q];
     rng.v3 = states[4 * n_items + q];
     rng.v4 = states[5 * n_items + q];
-    k = 0;
+    k = fr.k_begin;
     rays = 0;
     work_px = 0;
     color = splat(0.f);
+    if (fr.k_begin > 0) {  // (wave-uniform) resume: the first pass left the pixel's raw sum and ray count in the buffers
+      color = mk(out[q * 3 + 0], out[q * 3 + 1], out[q * 3 + 2]);
+      rays = ray_counts[q] & 0x7fffffffu;  // (bit 31: the scheduler's head mark on a mesh frame)
+    }
     has_px = true;
     return true;
   };
@@ -297,19 +301,19 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       // -- with the scheduler's probe behind the launch, its tile's rays per sample stand in as 64 samples' worth of
       // prior -- and, on a planned chain, what the probe said of the tiles still to come
       float left = 0.f;
-      if (has_px && (active || k < fr.spp)) {
+      if (has_px && (active || k < fr.k_end)) {
         float prior_rays = 8.f, prior_n = 1.f;
         if (lc.tile_cost != nullptr) prior_rays = 64.f * ((float)lc.tile_cost[q32 >> 6] * lc.rate_scale), prior_n = 64.f;
-        left = ((float)rays + prior_rays) * (float)(fr.spp - k + 1) * __builtin_amdgcn_rcpf((float)k + prior_n);
+        left = ((float)rays + prior_rays) * (float)(fr.k_end - k + 1) * __builtin_amdgcn_rcpf((float)k + prior_n);
         if (!(F & F_BVH) && lc.chain_next != nullptr && !heavy) left += (float)lc.chain_fut[q32 >> 6];
       }
       wave_priority_update(lc.prio_tab, (uint32_t)fminf(left, 4.0e9f));
     }
     // -------------------------------------------------------- sample / pixel bookkeeping
-    if (!active && !done && has_px && k >= fr.spp) {
+    if (!active && !done && has_px && k >= fr.k_end) {
       const int64_t q = (int64_t)q32;
       V3 c = color;
-      if (fr.post) {  // ray_tracing.cu:78-83
+      if (fr.post && fr.k_end >= fr.spp) {  // ray_tracing.cu:78-83 (a first pass leaves the raw sum)
         c = c / (float)fr.spp;
         c = mk(clamp1(c.x, 0.f, 1.f), clamp1(c.y, 0.f, 1.f), clamp1(c.z, 0.f, 1.f));
         c = mk(sqrtf(c.x), sqrtf(c.y), sqrtf(c.z));
@@ -335,7 +339,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       has_px = false;
     }
     const bool wave_heavy = (F & F_BVH) && lc.exclusive &&
-                            __builtin_amdgcn_ballot_w64(has_px && heavy && (active || k < fr.spp)) != 0ull;
+                            __builtin_amdgcn_ballot_w64(has_px && heavy && (active || k < fr.k_end)) != 0ull;
     if ((F & F_BVH) && classes) {
       const bool wants = !active && !done && !has_px;
       if (__builtin_amdgcn_ballot_w64(wants) != 0ull) {
@@ -346,7 +350,7 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
         // before each round
         for (int round = 0; round < 4; round++) {
           const int lvl = round == 0 ? 64 : round == 1 ? 32 : round == 2 ? 16 : 1;
-          const bool live_px = has_px && (active || k < fr.spp);
+          const bool live_px = has_px && (active || k < fr.k_end);
           int wave_cls = 1;
           if (lc.exclusive) {
             if (__builtin_amdgcn_ballot_w64(live_px && cls == 16) != 0ull) wave_cls = 16;

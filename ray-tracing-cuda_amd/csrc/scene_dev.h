@@ -274,6 +274,11 @@ enum : uint32_t {
 
 struct FrameDev {
   int32_t height, width, spp, max_depth, post;
+  // The samples THIS launch renders: [k_begin, k_end) of a pixel's spp (0 and spp for a frame rendered in one launch).
+  // A launch that starts behind sample 0 resumes every pixel from what the earlier launch left in the caller's buffers
+  // -- RNG state, raw radiance sum, ray count -- and only the launch that reaches spp post-processes.  A pixel's
+  // arithmetic is the same sequence of operations either way (render_body.h: take_item).
+  int32_t k_begin, k_end;
   int32_t rank, world;
   int32_t tiles_x, tiles_y, n_tiles;   // global tile grid
   int32_t local_tiles;                 // tiles owned by this rank

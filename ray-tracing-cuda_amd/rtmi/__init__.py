@@ -36,18 +36,18 @@ class RenderOpts(C.Structure):
                 ("threads_per_block", C.c_int32), ("sparse_stride", C.c_int32), ("exclusive", C.c_int32),
                 ("outlier_x10", C.c_int32), ("probe_spp", C.c_int32), ("head_pct", C.c_int32 * 3),
                 ("plan", C.c_int32), ("wave_priority", C.c_int32), ("lane_stride", C.c_int32),
-                ("promote_after", C.c_int32), ("cost_probe", C.c_int32),
+                ("promote_after", C.c_int32), ("cost_probe", C.c_int32), ("first_pass", C.c_int32), ("reserved", C.c_int32),
                 ("d_scratch", C.c_void_p), ("scratch_bytes", C.c_size_t)]
 
 
 def render_opts(schedule=-1, blocks_per_cu=0, threads_per_block=0, sparse_stride=0, exclusive=-1, outlier_x10=0,
                 probe_spp=0, head_pct=(0, 0, 0), scratch=None, plan=-1, wave_priority=-1, lane_stride=0, promote_after=-1,
-                cost_probe=-1):
+                cost_probe=-1, first_pass=-1):
     """``scratch``: a torch uint8/int32 CUDA tensor of at least ``scratch_bytes(frame)`` bytes that holds ALL
     per-call state of the render (keep it alive until the render has finished)."""
     o = RenderOpts(C.sizeof(RenderOpts), schedule, blocks_per_cu, threads_per_block, sparse_stride, exclusive,
                    outlier_x10, probe_spp, (C.c_int32 * 3)(*head_pct), plan, wave_priority, lane_stride, promote_after,
-                   cost_probe, None, 0)
+                   cost_probe, first_pass, 0, None, 0)
     if scratch is not None:
         o.d_scratch = scratch.data_ptr()
         o.scratch_bytes = scratch.numel() * scratch.element_size()

@@ -578,6 +578,9 @@ def test_scheduling_modes_do_not_change_a_bit():
              dict(schedule=2, plan=2, wave_priority=64, lane_stride=1, probe_spp=1),
              dict(schedule=0, plan=0, wave_priority=4, lane_stride=4),  # thin
              dict(schedule=2, plan=2, wave_priority=16, lane_stride=16),  # thin (the plan gives way to the queue)
+             dict(schedule=2, plan=2, wave_priority=16, lane_stride=1, first_pass=0),  # a discarded probe instead of a first pass
+             dict(schedule=2, plan=0, wave_priority=16, lane_stride=1, first_pass=4, probe_spp=0),  # a quarter of the samples first
+             dict(schedule=2, plan=2, wave_priority=16, lane_stride=1, first_pass=1, probe_spp=63),
              dict())  # the defaults
     for name, h, w, spp, depth in cases:
         b = common.build_scene(rtmi.SceneBuilder(common.scene_seed(name)), name, w / h).commit()

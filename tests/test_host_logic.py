@@ -321,7 +321,7 @@ def test_render_opts_validation():
     assert b"size" in L.rtmi_last_error()
     for kw in (dict(schedule=3), dict(threads_per_block=100), dict(threads_per_block=1024), dict(sparse_stride=12),
                dict(exclusive=2), dict(blocks_per_cu=-1), dict(probe_spp=65), dict(probe_spp=-1), dict(plan=3),
-               dict(wave_priority=12), dict(wave_priority=8192), dict(lane_stride=3), dict(lane_stride=128), dict(cost_probe=2)):
+               dict(wave_priority=12), dict(wave_priority=8192), dict(lane_stride=3), dict(lane_stride=128), dict(cost_probe=2), dict(first_pass=5000)):
         o = rtmi.render_opts(**kw)
         assert L.rtmi_render_ex(b.h, C.byref(fr), C.byref(o), dummy, dummy, None, None) == -1, kw
         assert b"out of range" in L.rtmi_last_error()

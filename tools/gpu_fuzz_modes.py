@@ -27,6 +27,8 @@ MODES = (dict(schedule=0, plan=0, wave_priority=0, lane_stride=1),
          dict(schedule=2, plan=2, wave_priority=2, lane_stride=1, blocks_per_cu=1),
          dict(schedule=2, plan=2, wave_priority=64, lane_stride=1, probe_spp=1, blocks_per_cu=2),
          dict(schedule=2, plan=0, wave_priority=8, lane_stride=4),
+         dict(schedule=2, plan=2, wave_priority=16, lane_stride=1, first_pass=0),
+         dict(schedule=2, plan=0, wave_priority=16, lane_stride=1, first_pass=3),
          dict())
 bad = 0
 t0 = time.time()
