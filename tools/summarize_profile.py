@@ -53,15 +53,25 @@ for wl in wls:
     scene, key = shape_of(wl)
     pmc = {}
     for d in ("pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_fetch", "pmc_write"):
-        per = {}
+        # One step = the trace kernel's launches of ONE rtmi_render call: the first pass (probe_kernel: the frame's own
+        # first samples since round 4, resumed by the second launch) + render_kernel.  Counters and durations of the two
+        # are added; the profiled commands run exactly one step, so the last launch of each name is that step's.
+        per, per_probe = {}, {}
         for r in rows("%s_%s/**/*counter_collection.csv" % (wl, d)):
             if "render_kernel" in r["Kernel_Name"]:
                 per.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            elif "probe_kernel" in r["Kernel_Name"]:
+                per_probe.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         for k, v in per.items():
-            pmc[k] = v[-1]
-        tr = [r for r in rows("%s_%s/**/*kernel_trace.csv" % (wl, d)) if "render_kernel" in r["Kernel_Name"]]
+            pmc[k] = v[-1] + (per_probe[k][-1] if k in per_probe else 0.0)
+        trace = rows("%s_%s/**/*kernel_trace.csv" % (wl, d))
+        tr = [r for r in trace if "render_kernel" in r["Kernel_Name"]]
+        tp = [r for r in trace if "probe_kernel" in r["Kernel_Name"]]
         if tr:
             pmc["_kernel_ms_" + d] = (int(tr[-1]["End_Timestamp"]) - int(tr[-1]["Start_Timestamp"])) / 1e6
+            if tp:
+                pmc["_first_pass_ms_" + d] = (int(tp[-1]["End_Timestamp"]) - int(tp[-1]["Start_Timestamp"])) / 1e6
+                pmc["_kernel_ms_" + d] += pmc["_first_pass_ms_" + d]
             pmc["_vgpr"], pmc["_sgpr"], pmc["_scratch"], pmc["_lds"] = (tr[-1]["VGPR_Count"], tr[-1]["SGPR_Count"],
                                                                       tr[-1]["Scratch_Size"], tr[-1]["LDS_Block_Size"])
     run = last_json(os.path.join(out, "%s_pmc_sq.log" % wl))
