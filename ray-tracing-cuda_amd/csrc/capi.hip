@@ -832,8 +832,12 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
       HIP_TRY(hipMemsetAsync(p_work, 0, n * 4, st));
       probe_plan.visit_counts = p_work;
     }
+    // (a first pass of the frame's own samples is a frame of s1 samples per pixel: from 32 on it has wave priorities too)
+    const bool first_prio = prio && resume && probe_spp >= 32 && env_int("RTMI_FIRST_PRIO", 1) != 0;
+    if (first_prio) probe_plan.prio_tab = plan.prio_tab;
     HIP_TRY(launch_render(variant, s->dev, probe, first_states, d_tiles, first_rays, counters, probe_plan, true, blocks,
                           threads, tune, params, st));
+    if (first_prio) HIP_TRY(hipMemsetAsync(plan.prio_tab, 0, kPrioTabBytes, st));
     if (resume) {
       // The scheduler's kernels read the first pass's ray counts and MARK the head's pixels in them (bit 31), and the
       // marks must outlive the pixels' final counts, which the second launch writes into the same words as it goes: they

@@ -625,7 +625,7 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.probe_spp = plan.probe_spp;
   lc.promote = tune.promote;
   lc.lane_stride = tune.lane_stride > 0 ? tune.lane_stride : 1;
-  lc.prio_tab = probe ? nullptr : plan.prio_tab;
+  lc.prio_tab = plan.prio_tab;  // (a first pass has one when it is long enough to gain from priorities: capi.hip)
   lc.tile_cost = plan.tile_cost;
   lc.rate_scale = 1.f / (64.f * (float)(plan.probe_spp > 0 ? plan.probe_spp : 1));
   lc.chain_next = (F & F_BVH) || lc.prio_tab == nullptr ? nullptr : plan.chain_next;
