@@ -279,7 +279,7 @@ typedef struct rtmi_render_opts {
                               * wave walks a CHAIN of tiles planned before the launch (tiles dealt to the SIMDs, then to a
                               * SIMD's waves, in snakes over the longest-first order, so that all chains of a SIMD and all
                               * SIMDs cost about the same; needs wave_priority); 2 = chains for any number of tiles */
-  int32_t wave_priority;     /* -1 default (16); 0 = the hardware's oldest-wave-first issue order; N (a power of two) = every
+  int32_t wave_priority;     /* -1 default (16; 4 on frames below 64 spp; none below 8 spp); 0 = the hardware's oldest-wave-first issue order; N (a power of two) = every
                               * N iterations a wave publishes how many queries it still has to do and takes the s_setprio
                               * level its rank among the waves of its SIMD gives it (longest remaining chain first) */
   int32_t lane_stride;       /* 0 default: list scenes, a frame with fewer pixels than the grid has lanes is spread thin, one
