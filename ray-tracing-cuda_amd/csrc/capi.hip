@@ -777,7 +777,11 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     const int div = tune.first_pass > 1 ? tune.first_pass : 16;
     probe_spp = !may_plan ? 2 : d.spp / div < 2 ? 2 : d.spp / div > 64 ? 64 : d.spp / div;
   }
-  const bool scheduled = tune.schedule == 2 || (tune.schedule == 1 && many_tiles && (two_pass ? d.spp >= 32 && d.spp >= 2 * probe_spp : d.spp >= 32 * probe_spp));
+  // (a first pass costs nothing but a launch, so short frames are scheduled too where it matters most: a mesh frame's
+  // outlier pixels -- the reference's own bunny program, 1280 x 720 x 20 spp: 7.3 -> 4.9 ms -- from 8 samples per pixel
+  // on; list frames from 32: at the reference's defaults, 100-200 spp, scheduled and unscheduled differ by +-4 %)
+  const int min_spp = two_pass ? ((variant & F_BVH) ? 8 : 32) : 32 * probe_spp;
+  const bool scheduled = tune.schedule == 2 || (tune.schedule == 1 && many_tiles && d.spp >= min_spp && d.spp >= 2 * probe_spp);
   // wave priorities (render_body.h: wave_priority_update) pay for themselves when a wave lives for many updates
   // ... from eight samples per pixel on; a short frame's waves live for tens of iterations, so they look every four
   // (C1, spheres 256^2 x 16 spp: 2.07 -> 1.86 ms; every 16: 1.89, every 2: 1.94, every iteration: 2.07)
