@@ -254,6 +254,7 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
     pristine = R.states.clone()
     opts = rtmi.render_opts(probe_spp=args.probe_spp) if args.probe_spp > 0 else None
     shape = R.launch_shape(opts)
+    mode = R.mode(opts)
     torch.cuda.synchronize()
     # (the exchange's tensors stay on the device with RCCL; the gloo test hook of main() takes them through the host)
     on_device = not (use_dist and dist.get_backend() == "gloo")
@@ -310,7 +311,7 @@ def run_workload(rtmi, torch, dist, w, args, rank, world, use_dist, steps, warmu
     n_simd = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count * 4
     pixels_rank = int((rtmi.pixel_map(R.frame) >= 0).sum())
     return dict(H=H, W=W, seed=seed, dt=dt, rays_rank=rays_rank, rays_all=rays_all, kern_ms=kern_ms, kern_ms_all=kerns,
-                per_rank_ms=per_rank_ms, n_seen=n_seen, bytes_per_ray=bytes_per_ray, n_simd=n_simd, shape=shape,
+                per_rank_ms=per_rank_ms, n_seen=n_seen, bytes_per_ray=bytes_per_ray, n_simd=n_simd, shape=shape, mode=mode,
                 pixels_rank=pixels_rank, items=R.items, scene=scene)
 
 
@@ -322,7 +323,7 @@ def extra_line(tag, w, r, steps, shard=None):
                          " -- shard %d of %d (what one GPU of %d renders)" % (shard[0], shard[1], shard[1]) if shard else ""),
             "value": r["rays_all"] * steps / r["dt"] / 1e6, "unit": "Mrays/s", "ms_per_step": r["dt"] / steps * 1e3,
             "kernel_ms": r["kern_ms"], "kernel_ms_min_max": [min(r["kern_ms_all"]), max(r["kern_ms_all"])],
-            "rays_per_step": r["rays_all"], "pixels": r["pixels_rank"], "resident_lanes": lanes,
+            "rays_per_step": r["rays_all"], "pixels": r["pixels_rank"], "resident_lanes": lanes, "schedule": r["mode"],
             "pixels_per_lane": r["pixels_rank"] / float(lanes),
             "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"], shard)}
 
@@ -516,6 +517,7 @@ def main():
                 "bytes_per_ray": r["bytes_per_ray"], "kernel_ms": max(r["per_rank_ms"]),
                 "kernel_ms_per_rank": r["per_rank_ms"], "n_ranks_seen": r["n_seen"],
                 "resident_lanes_per_rank": lanes, "pixels_per_lane": r["pixels_rank"] / float(lanes),
+                "schedule": r["mode"],  # rtmi_render_mode: first pass, planned chains or queue, priorities, lane stride
             },
             # (N > 1: rank 0's kernel is shard 0 of N of the frame -- the digest of exactly that shard, where there is one)
             "roofline": roofline(w, r["rays_rank"], r["kern_ms"], r["bytes_per_ray"], r["n_simd"],

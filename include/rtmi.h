@@ -307,6 +307,12 @@ size_t rtmi_render_scratch_bytes(const rtmi_frame *f);
  * workgroups per compute unit, compute units}.  workgroups x lanes = the lanes resident at once, each of which
  * holds one pixel at a time (utils.cu:158 fixes dim3(8,8) blocks over the whole frame instead). */
 int rtmi_render_launch_shape(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[4]);
+/* How a render of this frame would be scheduled on the current device (what rtmi_render_ex decides before it launches
+ * anything): out = {scheduled (1: a first pass orders / plans the rest), samples of the first pass (0: none), 1 if that
+ * pass is the frame's own first samples (resumed) and 0 if it is a discarded probe, 1 if the frame is rendered as
+ * planned chains (0: from the work queue), wave-priority interval in iterations (0: off), lane stride (1: every lane
+ * takes pixels), waves of the grid, tiles of this shard}.  Informational: none of it changes a pixel. */
+int rtmi_render_mode(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[8]);
 /* rtmi_render with per-call options (opts == NULL: the defaults). */
 int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
                    float *d_tiles, uint32_t *d_ray_counts, void *stream);

@@ -694,56 +694,14 @@ static int launch_shape(const Scene *s, const FrameDev &d, const RenderTuning &t
   return RTMI_OK;
 }
 
-int rtmi_render_launch_shape(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[4]) {
-  if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
-  const Scene *s = S(sp);
-  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
-  FrameDev d;
-  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
-  RenderTuning tune;
-  void *scratch;
-  size_t scratch_bytes;
-  int rc = resolve_opts(opts, &tune, &scratch, &scratch_bytes);
-  if (rc) return rc;
-  LaunchShape ls;
-  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
-  out[0] = ls.blocks, out[1] = ls.threads, out[2] = ls.per_cu, out[3] = ls.n_cu;
-  return RTMI_OK;
-}
-
-int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
-                   float *d_tiles, uint32_t *d_ray_counts, void *stream) {
-  if (!sp || !d_states || !d_tiles) return fail(RTMI_ERR_INVALID, "null argument");
-  RenderTuning tune;
-  void *user_scratch = nullptr;
-  size_t user_scratch_bytes = 0;
-  int rc = resolve_opts(opts, &tune, &user_scratch, &user_scratch_bytes);
-  if (rc) return rc;
-  const Scene *s = S(sp);
-  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
-  FrameDev d;
-  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
-  if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
-  LaunchShape ls;
-  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
-  const uint32_t variant = ls.variant;
-  const int threads = ls.threads, blocks = ls.blocks;
-  tune.lane_stride = ls.lane_stride;
-  hipStream_t st = (hipStream_t)stream;
-  const size_t need = scratch_bytes_of(d);
-  if (user_scratch && user_scratch_bytes < need)
-    return fail(RTMI_ERR_INVALID, "rtmi_render_opts.scratch_bytes < rtmi_render_scratch_bytes(frame)");
-  // Every piece of device state of this call -- queue cursors, ray total, abandoned-search flag, the scheduler's
-  // buffers -- lives in the caller's scratch when one is given: renders of one scene on several streams (or as N
-  // shards on one device) then share nothing but the read-only scene.  Without one the scene's own (a cache, not
-  // scene state) is used, which ties renders of this scene to one at a time.
-  unsigned long long *counters = user_scratch ? reinterpret_cast<unsigned long long *>(user_scratch) : s->d_counters;
-  // the kernels' argument blocks (kernels.hip: RenderParams): probe pass, real pass
-  char *params = user_scratch ? reinterpret_cast<char *>(user_scratch) + scratch_body_bytes(d) + kPrioTabBytes
-                              : reinterpret_cast<char *>(s->d_counters) + kCounterBytes;
-  // Longest-first tile order (kernels.hip): pays when lanes render several tiles each and a
-  // tile is long enough for the 2-spp probe to be cheap.
-  SchedPlan plan;
+// How a frame will be rendered: everything rtmi_render_ex decides before it launches anything (rtmi_render_mode reports
+// it).  `tune` is the call's tuning, already carrying the launch shape's lane stride; prio_every may be lowered here.
+struct RenderMode {
+  bool scheduled, resume, may_plan, prio;
+  int probe_spp;
+};
+static RenderMode decide_mode(const FrameDev &d, uint32_t variant, const LaunchShape &ls, RenderTuning &tune) {
+  const int blocks = ls.blocks, threads = ls.threads;
   const int64_t resident = (int64_t)blocks * threads;
   // When is a list frame planned?  The plan wins where the queue cannot even things out (few tiles per wave) AND its
   // estimates are good enough (long pixels: many samples).  Measured, planned against queued, cornell depth 50: 1.33
@@ -787,6 +745,92 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   // (C1, spheres 256^2 x 16 spp: 2.07 -> 1.86 ms; every 16: 1.89, every 2: 1.94, every iteration: 2.07)
   const bool prio = tune.prio_every > 0 && d.spp >= 8;
   if (prio && d.spp < 64 && tune.prio_every > 4) tune.prio_every = 4;
+  RenderMode m;
+  m.scheduled = scheduled, m.may_plan = may_plan, m.prio = prio, m.probe_spp = probe_spp;
+  m.resume = scheduled && two_pass && probe_spp < d.spp;
+  return m;
+}
+
+int rtmi_render_launch_shape(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[4]) {
+  if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
+  RenderTuning tune;
+  void *scratch;
+  size_t scratch_bytes;
+  int rc = resolve_opts(opts, &tune, &scratch, &scratch_bytes);
+  if (rc) return rc;
+  LaunchShape ls;
+  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
+  out[0] = ls.blocks, out[1] = ls.threads, out[2] = ls.per_cu, out[3] = ls.n_cu;
+  return RTMI_OK;
+}
+
+int rtmi_render_mode(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, int32_t out[8]) {
+  if (!sp || !out) return fail(RTMI_ERR_INVALID, "null argument");
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
+  RenderTuning tune;
+  void *scratch;
+  size_t scratch_bytes;
+  int rc = resolve_opts(opts, &tune, &scratch, &scratch_bytes);
+  if (rc) return rc;
+  LaunchShape ls;
+  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
+  tune.lane_stride = ls.lane_stride;
+  const RenderMode m = decide_mode(d, ls.variant, ls, tune);
+  const int waves = ls.blocks * (ls.threads / 64);
+  out[0] = m.scheduled ? 1 : 0;
+  out[1] = m.scheduled ? m.probe_spp : 0;
+  out[2] = m.resume ? 1 : 0;
+  const int simds = ls.n_cu * 4 < waves ? ls.n_cu * 4 : waves, rounds = simds > 0 ? (waves + simds - 1) / simds : 0;
+  out[3] = m.scheduled && m.may_plan && m.prio && simds * rounds <= kMaxChains ? 1 : 0;
+  out[4] = m.prio ? tune.prio_every : 0;
+  out[5] = ls.lane_stride;
+  out[6] = waves;
+  out[7] = d.local_tiles;
+  return RTMI_OK;
+}
+
+int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_opts *opts, void *d_states,
+                   float *d_tiles, uint32_t *d_ray_counts, void *stream) {
+  if (!sp || !d_states || !d_tiles) return fail(RTMI_ERR_INVALID, "null argument");
+  RenderTuning tune;
+  void *user_scratch = nullptr;
+  size_t user_scratch_bytes = 0;
+  int rc = resolve_opts(opts, &tune, &user_scratch, &user_scratch_bytes);
+  if (rc) return rc;
+  const Scene *s = S(sp);
+  if (!s->committed) return fail(RTMI_ERR_INVALID, "scene not committed");
+  FrameDev d;
+  if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
+  if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
+  LaunchShape ls;
+  if ((rc = launch_shape(s, d, tune, &ls))) return rc;
+  const uint32_t variant = ls.variant;
+  const int threads = ls.threads, blocks = ls.blocks;
+  tune.lane_stride = ls.lane_stride;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t need = scratch_bytes_of(d);
+  if (user_scratch && user_scratch_bytes < need)
+    return fail(RTMI_ERR_INVALID, "rtmi_render_opts.scratch_bytes < rtmi_render_scratch_bytes(frame)");
+  // Every piece of device state of this call -- queue cursors, ray total, abandoned-search flag, the scheduler's
+  // buffers -- lives in the caller's scratch when one is given: renders of one scene on several streams (or as N
+  // shards on one device) then share nothing but the read-only scene.  Without one the scene's own (a cache, not
+  // scene state) is used, which ties renders of this scene to one at a time.
+  unsigned long long *counters = user_scratch ? reinterpret_cast<unsigned long long *>(user_scratch) : s->d_counters;
+  // the kernels' argument blocks (kernels.hip: RenderParams): probe pass, real pass
+  char *params = user_scratch ? reinterpret_cast<char *>(user_scratch) + scratch_body_bytes(d) + kPrioTabBytes
+                              : reinterpret_cast<char *>(s->d_counters) + kCounterBytes;
+  // Longest-first tile order, first pass, plan, priorities: decide_mode
+  SchedPlan plan;
+  const RenderMode mode = decide_mode(d, variant, ls, tune);
+  const bool scheduled = mode.scheduled, may_plan = mode.may_plan, prio = mode.prio;
+  const int probe_spp = mode.probe_spp;
   void *scratch = user_scratch;
   if (!scratch && (scheduled || prio)) {
     Scene *ms = const_cast<Scene *>(s);
@@ -821,7 +865,7 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
     // mesh frames (binary32 t): the probe also books the lane-steps of its mesh searches on the pixels they serve
     const bool by_cost = tune.cost_probe && (variant & F_BVH) && !(variant & F_SPHERE);
     // first pass: the frame's own samples [0, probe_spp) into the caller's buffers, or a discarded probe on copies
-    const bool resume = two_pass && probe_spp < d.spp;
+    const bool resume = mode.resume;
     uint32_t *first_states = resume ? reinterpret_cast<uint32_t *>(d_states) : p_states;
     uint32_t *first_rays = resume && d_ray_counts ? d_ray_counts : p_rays;
     if (!resume) HIP_TRY(hipMemcpyAsync(p_states, d_states, n * RTMI_STATE_WORDS * 4, hipMemcpyDeviceToDevice, st));

@@ -108,6 +108,7 @@ SYMBOLS = [
     ("rtmi_render_ex", C.c_int, [C.c_void_p, _frp, C.POINTER(RenderOpts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rtmi_render_scratch_bytes", C.c_size_t, [_frp]),
     ("rtmi_render_launch_shape", C.c_int, [C.c_void_p, _frp, C.POINTER(RenderOpts), C.POINTER(C.c_int32)]),
+    ("rtmi_render_mode", C.c_int, [C.c_void_p, _frp, C.POINTER(RenderOpts), C.POINTER(C.c_int32)]),
     ("rtmi_render_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     ("rtmi_last_ray_total", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
     ("rtmi_debug_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_void_p]),
@@ -371,6 +372,15 @@ class Renderer:
                                                    C.byref(opts) if opts is not None else None, out),
                    "rtmi_render_launch_shape")
         return dict(zip(("blocks", "threads", "blocks_per_cu", "compute_units"), list(out)))
+
+    def mode(self, opts=None):
+        """How a render of this frame would be scheduled (rtmi_render_mode)."""
+        out = (C.c_int32 * 8)()
+        with self.torch.cuda.device(self.device):
+            _check(self.L.rtmi_render_mode(self.scene.h, C.byref(self.frame), C.byref(opts) if opts is not None else None, out),
+                   "rtmi_render_mode")
+        return dict(zip(("scheduled", "first_pass_samples", "first_pass_resumed", "planned_chains", "wave_priority_every",
+                         "lane_stride", "waves", "tiles"), list(out)))
 
     def total_rays(self, scratch=None):
         """Closest-hit queries of the last render (of the one that used ``scratch``, if given); raises when that

@@ -620,6 +620,35 @@ def test_bench_shard_and_sweep_paths():
     assert line["n_gpus"] == 1 and "shard 1 only" in line["config"]["workload"] and line["value"] > 0
 
 
+def test_render_mode_reports_the_schedule_of_the_baseline_configs():
+    """rtmi_render_mode: what rtmi_render_ex decides before it launches anything, on BASELINE's five configurations (their
+    frame shapes; nothing is rendered): C2 and the C4 / C5 shards are planned chains after a first pass of the frame's own
+    samples, the mesh frame comes from the queue after two, C1 is a thin unscheduled frame with priorities every four."""
+    import rtmi
+    import common
+    def mode(name, side, spp, depth, rank=0, world=1, **kw):
+        b = common.build_scene(rtmi.SceneBuilder(common.scene_seed(name)), name, 1.0).commit()
+        R = rtmi.Renderer(b, side, side, spp, depth, True, rank=rank, world_size=world)
+        return R.mode(rtmi.render_opts(**kw) if kw else None)
+    c2 = mode("cornell_box", 1024, 1024, 50)
+    assert c2["scheduled"] == 1 and c2["first_pass_resumed"] == 1 and c2["first_pass_samples"] == 64 and c2["planned_chains"] == 1
+    assert c2["wave_priority_every"] == 16 and c2["lane_stride"] == 1 and c2["tiles"] == 16384 and c2["tiles"] <= 3 * c2["waves"]
+    c4 = mode("cornell_box", 2048, 4096, 50, rank=3, world=8)
+    assert c4["planned_chains"] == 1 and c4["first_pass_samples"] == 64 and c4["tiles"] == 8192
+    c5 = mode("birthday", 4096, 8192, 10, rank=0, world=8)
+    assert c5["planned_chains"] == 1 and c5["tiles"] == 32768 and c5["tiles"] <= 8 * c5["waves"]
+    c3 = mode("bunny", 1024, 512, 10)
+    assert c3["scheduled"] == 1 and c3["first_pass_samples"] == 2 and c3["first_pass_resumed"] == 1 and c3["planned_chains"] == 0
+    c1 = mode("spheres", 256, 16, 8)
+    assert c1["scheduled"] == 0 and c1["first_pass_samples"] == 0 and c1["lane_stride"] == 4 and c1["wave_priority_every"] == 4
+    # per-call options reach the decision
+    assert mode("cornell_box", 1024, 1024, 50, plan=0)["planned_chains"] == 0
+    assert mode("cornell_box", 1024, 1024, 50, first_pass=0)["first_pass_resumed"] == 0
+    assert mode("cornell_box", 1024, 1024, 50, schedule=0)["scheduled"] == 0
+    assert mode("cornell_box", 1024, 1024, 50, wave_priority=0) ["planned_chains"] == 0  # the plan needs the priorities
+    assert mode("cornell_box", 1024, 128, 50)["planned_chains"] == 0  # 2.67 tiles per wave at 128 spp: the queue
+
+
 def test_bench_n_rank_code_with_real_rendering_on_one_gpu():
     """bench.py --gpus 2 and 3 with its one-GPU test hook (every rank on cuda:0, exchange over gloo): the N-rank code of
     the bench -- per-rank shards, barrier-bracketed timing, max over ranks, the gather of the tile buffers, untile on rank
