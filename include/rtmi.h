@@ -65,7 +65,8 @@ typedef struct rtmi_scene rtmi_scene; /* opaque; replaces the device-resident Hi
 typedef struct rtmi_frame {
   int32_t height;       /* 1 .. RTMI_MAX_EXTENT (the reference has no such limit: a pixel's row and column share one */
   int32_t width;        /* 32-bit register of the trace kernel); a larger frame is refused with RTMI_ERR_INVALID */
-  int32_t spp;          /* samples per pixel rendered by THIS call */
+  int32_t spp;          /* samples per pixel rendered by THIS call; spp * (max_depth + 1) <= RTMI_MAX_PIXEL_QUERIES (a */
+                        /* pixel's closest-hit queries are counted in 31 bits), else rtmi_render refuses the frame */
   int32_t max_depth;    /* TRACE_DEPTH_LIMIT, ray_tracing.cu:10,23 */
   int32_t post_process; /* 1: out = sqrt(clamp(sum/spp,0,1)) (ray_tracing.cu:78-83); 0: raw sum */
   int32_t rank;         /* tile shard owner, 0 <= rank < world_size */
@@ -73,6 +74,7 @@ typedef struct rtmi_frame {
 } rtmi_frame;
 
 #define RTMI_MAX_EXTENT 65535
+#define RTMI_MAX_PIXEL_QUERIES 2147483647
 const char *rtmi_last_error(void);
 int rtmi_version(void);
 /* Number of usable GPUs (0 when there is none); never fails. */

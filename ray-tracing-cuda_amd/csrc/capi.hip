@@ -809,6 +809,10 @@ int rtmi_render_ex(const rtmi_scene *sp, const rtmi_frame *f, const rtmi_render_
   FrameDev d;
   if (!make_frame(f, &d)) return fail(RTMI_ERR_INVALID, frame_why("bad frame"));
   if (d.max_depth < 0 || d.max_depth > RTMI_MAX_DEPTH) return fail(RTMI_ERR_DEPTH, "max_depth outside [0, 64]");
+  // a pixel's closest-hit queries (at most max_depth + 1 per sample, ray_tracing.cu:22) are counted in 31 bits of its
+  // ray_counts word (bit 31: the scheduler's mark) and of the trace kernel's register
+  if ((int64_t)d.spp * (d.max_depth + 1) > (int64_t)RTMI_MAX_PIXEL_QUERIES)
+    return fail(RTMI_ERR_INVALID, "spp x (max_depth + 1) above 2^31 - 1 (RTMI_MAX_PIXEL_QUERIES): a pixel's closest-hit queries are counted in 31 bits");
   LaunchShape ls;
   if ((rc = launch_shape(s, d, tune, &ls))) return rc;
   const uint32_t variant = ls.variant;

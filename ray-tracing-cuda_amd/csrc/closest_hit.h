@@ -741,7 +741,8 @@ __device__ __forceinline__ Hit closest_hit(const SceneDev &sc, const BvhNode *s_
           for (int j = 0; j < kHitSlots; j++) nleaf += (uint32_t)hs[j].x != kCodeNone ? 1 : 0;
           const int depth_r = br.ref_depth;
           const int log_d = depth_r < 8 ? 3 : depth_r < 16 ? 4 : 5;  // a leaf's row: its path code + the crossing times, 8, 16 or 32 words
-          const int rows_max = (kMeshStackWords - 64) >> log_d;
+          // (rows of this round: `leaves` holds 64 of them, `times` the rest of the stack's words)
+          const int rows_max = (kMeshStackWords - 64) >> log_d < 64 ? (kMeshStackWords - 64) >> log_d : 64;
           // exclusive prefix sum of nleaf (0..4) over the wave in registers: no LDS round trips
           const int base = wave_prefix_excl(nleaf);
           int *leaves = wl + 64 * kMeshRayWords;  // [64] one word per listed leaf of this round

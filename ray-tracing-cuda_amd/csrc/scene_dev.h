@@ -170,8 +170,9 @@ constexpr int kHitWords = 3;    // words per entry: code, face, t (binary32: Tri
 // [16..27] kHitSlots x (code, face, t).
 constexpr int kMeshRayWords = 16 + kHitSlots * kHitWords;
 constexpr int kMeshStackWords = 512;  // node entries grow up from 0, face-block entries down from the top
-                                      // (256 words: C3 +27 % time; larger stacks are NOT supported by the search's entry
-                                      // arithmetic -- a 768-word build faulted, NOTES.md round 4)
+                                      // (256 words: C3 +27 % time.  A 768-word build faulted in round 4: the replay's
+                                      // 64-word `leaves` array was sized by this constant, closest_hit.h -- now capped
+                                      // there; a larger stack also costs the third workgroup per CU its LDS)
 constexpr int kMeshWaveWords = 64 * kMeshRayWords + kMeshStackWords;
 constexpr uint32_t kCodeNone = 0xffffffffu;  // "no cut": no leaf code has bit 0 set (kRefDepthMax = 31)
 constexpr int kSparseStride = 16;  // outlier tiles of mesh frames: one pixel per this many lanes (power of two)

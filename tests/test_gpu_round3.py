@@ -256,6 +256,26 @@ def test_render_status_and_single_rank_gather():
     assert L.rtmi_reduce_sum(None, C.byref(R.frame), C.c_void_p(R.tiles.data_ptr()), 0, None) == 0
 
 
+def test_a_frame_whose_pixels_could_overrun_their_query_counter_is_refused():
+    """A pixel's closest-hit queries -- at most max_depth + 1 per sample (ray_tracing.cu:22-26) -- are counted in 31 bits
+    (bit 31 of its ray_counts word is the scheduler's mark): rtmi_render refuses spp * (max_depth + 1) > 2^31 - 1 and says
+    why, instead of wrapping the counter (the reference counts nothing; include/rtmi.h: RTMI_MAX_PIXEL_QUERIES)."""
+    import common
+    import os
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "rtmi.h")).read()
+    assert "#define RTMI_MAX_PIXEL_QUERIES 2147483647" in hdr
+    L = rtmi.lib()
+    b = common.build_scene(rtmi.SceneBuilder(1024), "cornell_box", 1.0).commit()
+    for spp, depth in (((1 << 31) - 1, 1), ((1 << 31) // 11 + 1, 10), ((1 << 31) // 65 + 1, 64)):
+        R = rtmi.Renderer(b, 8, 8, spp, depth).init_rng()
+        with pytest.raises(Exception):
+            R.render()
+        assert b"RTMI_MAX_PIXEL_QUERIES" in L.rtmi_last_error()
+    R = rtmi.Renderer(b, 8, 8, 3, 64).init_rng()  # (the deepest legal depth renders)
+    R.render()
+    assert R.total_rays() > 0
+
+
 # ------------------------------------------------------------------ long sphere runs (grouped scan)
 @pytest.mark.parametrize("n,seed", [(32, 0), (33, 1), (100, 2), (257, 3), (700, 4)])
 def test_long_sphere_runs_match_the_full_scan(n, seed):
