@@ -632,6 +632,16 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
   lc.chain_fut = plan.chain_fut, lc.chain_first = plan.chain_first, lc.claims = plan.claims;
   lc.plan_simds = plan.plan_simds, lc.plan_rounds = plan.plan_rounds;
   lc.prio_every = tune.prio_every > 0 ? tune.prio_every : 16;
+  {  // (render_body.h: the wave draws from the queue in batches; RTMI_FETCH_BATCH / RTMI_FETCH_BATCH_FIRST: A/B measurements)
+    static const int batch_main = [] { const char *e = getenv("RTMI_FETCH_BATCH"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+    static const int batch_first = [] { const char *e = getenv("RTMI_FETCH_BATCH_FIRST"); const int v = e ? atoi(e) : 64; return v < 1 ? 1 : v > 64 ? 64 : v; }();
+    // a first pass of a few samples: whole tiles; longest-first order: 16 (measured 4 / 16 / 64 on frames of 2.3 ...
+    // 12.8 pixels per lane, NOTES.md); image order, or a first pass as long as a frame: the lanes that wait
+    // (a pooled item waits for a lane of its wave: the longer a pixel takes, the fewer -- from 4,096 samples on, none)
+    const int samples = fr.k_end - fr.k_begin > 0 ? fr.k_end - fr.k_begin : 1;
+    const int by_length = 4096 / samples < 1 ? 1 : 4096 / samples;
+    lc.fetch_batch = probe && samples <= 4 ? batch_first : plan.tile_order != nullptr ? (by_length < batch_main ? by_length : batch_main) : 1;
+  }
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
     hipError_t e = hipFuncSetAttribute(probe ? reinterpret_cast<const void *>(probe_kernel<F>)
                                              : reinterpret_cast<const void *>(render_kernel<F>),

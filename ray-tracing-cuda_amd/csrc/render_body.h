@@ -50,6 +50,7 @@ struct LaunchCfg {
                                  // wave that has nothing left takes the lightest tile nobody has started (cursor:
                                  // counters[36], from the far end of tile_order, which in this mode is per TILE), so
                                  // every tile is rendered whatever the hardware's placement of the waves was
+  int32_t fetch_batch;           // list variants, queue mode: items a wave takes from the queue per atomic, at most (1..64)
   const uint32_t *tile_cost;     // optional: the probe's ray count per tile (64 pixels x probe_spp samples): a pixel's
   float rate_scale;              // rays per sample are first taken as tile_cost x rate_scale = 1 / (64 probe_spp)
 };
@@ -282,6 +283,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
   RTMI_STAT(MeshStats st = {}; unsigned wave_queries = 0; const unsigned long long t_begin = stat_real();
             const unsigned long long t_begin_rt = __builtin_amdgcn_s_memrealtime();)
   uint32_t prio_tick = 0u;  // (wave-uniform)
+  uint32_t pool_at = 0u, pool_end = 0u;  // (wave-uniform) list variants: the wave's share of the queue, [pool_at, pool_end)
+  bool queue_dry = false;                // (wave-uniform) ... and the queue has nothing more to give
   // A frame with fewer pixels than the grid has lanes (C1: 65,536 on 262,144) is spread THIN: one pixel per
   // lane_stride lanes, so that every SIMD gets a wave and a wave's shared candidate tests serve 16 rays with 64 lanes
   // instead of 64 rays on a quarter of the SIMDs.  The idle lanes never fetch; they work in closest_hit.
@@ -423,6 +426,52 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
           (void)take_item((int64_t)t * 64 + (int64_t)(threadIdx.x & 63u));
           if (__builtin_amdgcn_ballot_w64(has_px) != 0ull) break;  // (a tile of padding only: look further)
         }
+      }
+    } else if (!(F & F_BVH)) {
+      // The queue of a list frame, drawn by the WAVE: one atomic takes the next `batch` items for all its lanes, which
+      // help themselves from that pool as they finish their pixels.  Every atomic on the queue's cursor is a round
+      // trip to the one L2 channel that owns its line, and they are served there one after the other (5.5 ns each,
+      // measured): with one per pixel a first pass of two samples over a million pixels was 3.8 ms of atomics around
+      // 0.55 ms of rendering.  `batch` shrinks with what is left of the queue (at most half a wave's fair share of it),
+      // so that no wave sits on items while others have run dry; lc.fetch_batch = 1 is one atomic per fetch for the
+      // lanes that wait at that moment -- the queue of rounds 1-3, kept for frames in image order, whose last tiles
+      // weigh as much as any.
+      for (;;) {
+        const bool wants = !active && !done && !has_px;
+        const unsigned long long wm = __builtin_amdgcn_ballot_w64(wants);
+        if (wm == 0ull) break;
+        if (pool_at == pool_end) {
+          unsigned long long nq = 0ull;
+          if (!queue_dry) {
+            const uint32_t left = (uint32_t)n_items - pool_end;  // (what the cursor had left after this wave's last draw)
+            uint32_t batch = left / (2u * (gridDim.x * (n_threads >> 6)));
+            batch = batch < 1u ? 1u : batch > (uint32_t)lc.fetch_batch ? (uint32_t)lc.fetch_batch : batch;
+            const uint32_t asked = (uint32_t)__popcll(wm);  // (never less than the lanes that are waiting right now)
+            batch = batch < asked ? asked : batch;
+            if ((threadIdx.x & 63u) == 0u) nq = atomicAdd(&counters[0], (unsigned long long)batch);
+            nq = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nq >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)nq);
+            if (nq < (unsigned long long)n_items) {
+              pool_at = (uint32_t)nq;
+              pool_end = nq + batch < (unsigned long long)n_items ? (uint32_t)nq + batch : (uint32_t)n_items;
+            } else {
+              queue_dry = true;
+            }
+          }
+          if (queue_dry) {
+            done = done || wants;
+            break;
+          }
+        }
+        const uint32_t avail = pool_end - pool_at, want_n = (uint32_t)__popcll(wm);
+        const uint32_t rank = (uint32_t)lane_rank(wm);
+        if (wants && rank < avail) {
+          const uint32_t nq = pool_at + rank;
+          int64_t item = (int64_t)nq;
+          if (lc.tile_order) item = (int64_t)lc.tile_order[nq >> 4] * 16 + (int64_t)(nq & 15u);
+          (void)take_item(item);  // (padding: the lane still wants, and looks again)
+        }
+        pool_at += want_n < avail ? want_n : avail;
       }
     } else if (!active && !done) {
       while (!has_px && !done) {

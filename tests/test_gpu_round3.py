@@ -619,6 +619,34 @@ def test_scheduling_modes_do_not_change_a_bit():
                 assert np.array_equal(x, y), (name, kw)
 
 
+def test_the_queue_drawn_in_batches_renders_every_pixel_once():
+    """List frames take their work items from the queue a batch per WAVE and atomic (render_body.h: up to 64 in a first
+    pass of a few samples, up to 16 in longest-first order, fewer towards the end of the queue, the waiting lanes only in
+    image order).  Ragged frames (padding items inside the batches), shards, a grid of one workgroup per CU (hundreds of
+    items per wave: full batches) and of one block only: same image, ray counts and RNG states as the image-order queue."""
+    import common
+    cases = (("cornell_box", 250, 203, 40, 12, 0, 1), ("spheres", 264, 200, 36, 8, 0, 1), ("cornell_box", 333, 517, 33, 6, 1, 3),
+             ("birthday", 200, 264, 34, 10, 2, 3))
+    modes = (dict(schedule=0, wave_priority=0), dict(schedule=2, plan=0), dict(schedule=2, plan=0, blocks_per_cu=1),
+             dict(schedule=2, plan=0, blocks_per_cu=1, probe_spp=1), dict(schedule=2, plan=0, blocks_per_cu=1, first_pass=0),
+             dict(schedule=2, plan=0, blocks_per_cu=1, threads_per_block=64), dict())
+    for name, h, w, spp, depth, rank, world in cases:
+        b = common.build_scene(rtmi.SceneBuilder(common.scene_seed(name)), name, w / h).commit()
+        want = None
+        for kw in modes:
+            R = rtmi.Renderer(b, h, w, spp, depth, True, rank=rank, world_size=world).init_rng()
+            R.render(opts=rtmi.render_opts(**kw))
+            R.check()
+            got = (R.tiles.cpu().numpy(), R.ray_counts.cpu().numpy(), R.states.cpu().numpy(), R.total_rays())
+            if want is None:
+                want = got
+                assert got[3] > (h * w // world) * spp // 2
+                continue
+            assert got[3] == want[3], (name, kw)
+            for x, y in zip(got[:3], want[:3]):
+                assert np.array_equal(x, y, equal_nan=True), (name, kw)
+
+
 def test_bench_shard_and_sweep_paths():
     """bench.py --shard r/G and --shard-sweep G on a small workload: the one-GPU estimate of G-GPU strong scaling (each
     shard rendered as rank r of G would render it).  The shards' ray totals add up to the full frame's."""
