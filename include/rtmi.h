@@ -323,7 +323,9 @@ int rtmi_render_ex(const rtmi_scene *s, const rtmi_frame *f, const rtmi_render_o
  * Kept for callers of the first ABI version; prefer rtmi_render_opts.  The RTMI_SPARSE_STRIDE /
  * RTMI_EXCLUSIVE / RTMI_OUTLIER_X10 / RTMI_HEAD_CLASSES (0: tiles) / RTMI_PROBE_SPP / RTMI_PLAN / RTMI_PRIO (wave_priority) /
  * RTMI_LANE_STRIDE / RTMI_PROMOTE (promote_after) / RTMI_COST_PROBE / RTMI_FIRST_PASS environment variables override the built-in defaults
- * of those fields and are read once, when the library is first used. */
+ * of those fields and are read once, when the library is first used.  (RTMI_FETCH_BATCH / RTMI_FETCH_BATCH_FIRST, 1..64: the
+ * largest batch a wave of a list frame draws from the work queue per atomic in longest-first order / in a first pass of a
+ * few samples -- measurement knobs without an option field; defaults 16 / 64.) */
 int rtmi_set_launch(int blocks_per_cu, int threads_per_block);
 int rtmi_set_schedule(int mode);
 
