@@ -434,8 +434,8 @@ __device__ __forceinline__ void render_body(const SceneDev &sc, const FrameDev &
       // measured): with one per pixel a first pass of two samples over a million pixels was 3.8 ms of atomics around
       // 0.55 ms of rendering.  `batch` shrinks with what is left of the queue (at most half a wave's fair share of it),
       // so that no wave sits on items while others have run dry; lc.fetch_batch = 1 is one atomic per fetch for the
-      // lanes that wait at that moment -- the queue of rounds 1-3, kept for frames in image order, whose last tiles
-      // weigh as much as any.
+      // lanes that wait at that moment -- the queue of rounds 1-3, kept for image-order frames of 64 samples and more,
+      // whose last tiles weigh as much as any (kernels.hip: launch_render_t).
       for (;;) {
         const bool wants = !active && !done && !has_px;
         const unsigned long long wm = __builtin_amdgcn_ballot_w64(wants);
