@@ -643,7 +643,10 @@ static hipError_t launch_render_t(const SceneDev &sc, const FrameDev &fr, uint32
     // image order (a frame too short to be scheduled, or a first pass as long as a frame): its last tiles weigh as much as
     // any, so batches only where the atomics would otherwise be the frame -- cornell 1024^2 x 16 spp: 8.0 ms a pixel at
     // a time, 5.2 ms four at a time; at 200 spp sixteen at a time cost 8 %
-    const int image_batch = 64 / samples < 1 ? 1 : 64 / samples > 16 ? 16 : 64 / samples;
+    // (below 32 spp -- where list frames are not scheduled -- 256 / samples: at 24 spp two pixels per atomic left a 2048^2
+    // frame at the cursor's rate, 23.8 ms against 22.1 ms for 32 spp)
+    const int per_atomic = samples < 32 ? 256 / samples : 64 / samples;
+    const int image_batch = per_atomic < 1 ? 1 : per_atomic > 16 ? 16 : per_atomic;
     lc.fetch_batch = probe && samples <= 4 ? batch_first : plan.tile_order != nullptr ? (by_length < batch_main ? by_length : batch_main) : image_batch;
   }
   if (lds > 64 * 1024) {  // above the default dynamic-LDS limit: ask for it (160 KiB per CU on gfx950)
